@@ -1,0 +1,41 @@
+# Build recipe for the HIP renderer (fray_amd/libfrayhip.so), the CPU oracle
+# (oracle/libfray_oracle.so) and, when /root/reference is present, the partial reference build
+# (oracle/_ref/libfray_ref.so).  __graft_entry__.build() runs `make all`.
+HIPCC   ?= /opt/rocm/bin/hipcc
+CXX     ?= g++
+ARCH    ?= gfx950
+INC     := -Iinclude -Ifray_amd/csrc
+# -ffp-contract=off: the reference build has no FMA contraction (x86-64 baseline); bit-exact hit
+# records need the same on the device.
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $(INC)
+CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off $(INC)
+
+HOST_SRC := fray_amd/csrc/host_scene.cpp fray_amd/csrc/host_loaders.cpp fray_amd/csrc/host_exr.cpp
+HOST_OBJ := $(HOST_SRC:.cpp=.o)
+HIP_SRC  := fray_amd/csrc/capi.hip
+HIP_OBJ  := $(HIP_SRC:.hip=.o)
+HIP_HDR  := $(wildcard fray_amd/csrc/*.h) $(wildcard fray_amd/csrc/*.hpp) include/frayhip.h
+
+all: fray_amd/libfrayhip.so oracle/libfray_oracle.so ref
+
+fray_amd/csrc/%.o: fray_amd/csrc/%.cpp $(HIP_HDR)
+	$(CXX) $(CXXFLAGS) -c $< -o $@
+
+fray_amd/csrc/%.o: fray_amd/csrc/%.hip $(HIP_HDR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+fray_amd/libfrayhip.so: $(HOST_OBJ) $(HIP_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
+oracle/libfray_oracle.so: oracle/fray_oracle.cpp include/frayhip.h
+	$(CXX) $(CXXFLAGS) -shared -pthread -o $@ $<
+
+# Partial reference build: only when the reference tree is mounted (never on the GPU box).
+ref:
+	@if [ -d /root/reference/src ]; then $(MAKE) -C oracle -f Makefile.ref; else echo "reference tree absent: oracle/_ref not rebuilt"; fi
+
+clean:
+	rm -f fray_amd/csrc/*.o fray_amd/libfrayhip.so oracle/libfray_oracle.so
+	rm -rf oracle/_ref
+
+.PHONY: all ref clean

@@ -1,0 +1,79 @@
+// C ABI, host-only entry points (no HIP calls): scene parsing and small utilities.
+#include <cmath>
+#include <cstring>
+#include <string>
+
+#include "capi_common.h"
+#include "host_scene.h"
+
+namespace frayhip_detail {
+thread_local std::string g_last_error;
+void set_error(const std::string& s) { g_last_error = s; }
+}  // namespace frayhip_detail
+
+struct frayhip_host_scene {
+    frayhost::HostScene* hs;
+};
+
+extern "C" {
+
+int frayhip_scene_parse(const char* fray_path, frayhip_host_scene** out)
+{
+    if (!fray_path || !out) { frayhip_detail::set_error("frayhip_scene_parse: null argument"); return FRAYHIP_E_ARG; }
+    std::string err;
+    frayhost::HostScene* hs = frayhost::parse_scene_file(fray_path, err);
+    if (!hs) { frayhip_detail::set_error(err); return FRAYHIP_E_PARSE; }
+    *out = new frayhip_host_scene{hs};
+    return FRAYHIP_OK;
+}
+
+frayhip_scene_desc* frayhip_host_scene_desc(frayhip_host_scene* hs) { return hs ? &hs->hs->desc : nullptr; }
+
+void frayhip_host_scene_free(frayhip_host_scene* hs)
+{
+    if (!hs) return;
+    delete hs->hs;
+    delete hs;
+}
+
+int frayhip_bucket_count(int width, int height, int bucket_first, int bucket_stride)
+{
+    if (width <= 0 || height <= 0 || bucket_stride <= 0 || bucket_first < 0 || bucket_first >= bucket_stride) return FRAYHIP_E_ARG;
+    int total = ((width - 1) / 48 + 1) * ((height - 1) / 48 + 1);
+    return (total - bucket_first + bucket_stride - 1) / bucket_stride;
+}
+
+// convertTo8bit / Color::toRGB32 (color.h:29-34, 59-65): clamp, floor(x*255 + 0.5), 0x00RRGGBB.
+int frayhip_to_rgb32(const float* rgb, uint32_t* out, int n_pixels)
+{
+    if (!rgb || !out || n_pixels < 0) return FRAYHIP_E_ARG;
+    for (int i = 0; i < n_pixels; i++) {
+        uint32_t c[3];
+        for (int k = 0; k < 3; k++) {
+            float x = rgb[i * 3 + k];
+            if (x < 0) x = 0;
+            if (x > 1) x = 1;
+            c[k] = (uint32_t)(int)floor(x * 255.0f + 0.5f);
+        }
+        out[i] = (c[2]) | (c[1] << 8) | (c[0] << 16);
+    }
+    return FRAYHIP_OK;
+}
+
+const char* frayhip_last_error(void) { return frayhip_detail::g_last_error.c_str(); }
+int frayhip_abi_version(void) { return FRAYHIP_ABI_VERSION; }
+
+int frayhip_sizeof(const char* n)
+{
+    if (!n) return -1;
+#define FRAYHIP_SZ(T) if (!strcmp(n, #T)) return (int)sizeof(T);
+    FRAYHIP_SZ(frayhip_transform) FRAYHIP_SZ(frayhip_geom_ref) FRAYHIP_SZ(frayhip_node) FRAYHIP_SZ(frayhip_plane)
+    FRAYHIP_SZ(frayhip_sphere) FRAYHIP_SZ(frayhip_cube) FRAYHIP_SZ(frayhip_csg) FRAYHIP_SZ(frayhip_triangle)
+    FRAYHIP_SZ(frayhip_kdnode) FRAYHIP_SZ(frayhip_mesh) FRAYHIP_SZ(frayhip_texture) FRAYHIP_SZ(frayhip_shader)
+    FRAYHIP_SZ(frayhip_layer) FRAYHIP_SZ(frayhip_light) FRAYHIP_SZ(frayhip_camera) FRAYHIP_SZ(frayhip_settings)
+    FRAYHIP_SZ(frayhip_environment) FRAYHIP_SZ(frayhip_scene_desc) FRAYHIP_SZ(frayhip_frame) FRAYHIP_SZ(frayhip_stats)
+#undef FRAYHIP_SZ
+    return -1;
+}
+
+}  // extern "C"

@@ -7,10 +7,10 @@ ARCH    ?= gfx950
 INC     := -Iinclude -Ifray_amd/csrc
 # -ffp-contract=off: the reference build has no FMA contraction (x86-64 baseline); bit-exact hit
 # records need the same on the device.
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $(INC)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt $(INC)
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off $(INC)
 
-HOST_SRC := fray_amd/csrc/host_scene.cpp fray_amd/csrc/host_loaders.cpp fray_amd/csrc/host_exr.cpp
+HOST_SRC := fray_amd/csrc/host_scene.cpp fray_amd/csrc/host_loaders.cpp fray_amd/csrc/host_exr.cpp fray_amd/csrc/capi_host.cpp
 HOST_OBJ := $(HOST_SRC:.cpp=.o)
 HIP_SRC  := fray_amd/csrc/capi.hip
 HIP_OBJ  := $(HIP_SRC:.hip=.o)

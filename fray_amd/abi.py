@@ -16,6 +16,7 @@ TEX_CHECKER, TEX_BITMAP, TEX_BUMP, TEX_FRESNEL = range(4)
 SHADER_CONST, SHADER_LAMBERT, SHADER_PHONG, SHADER_REFL, SHADER_REFR, SHADER_LAYERED = range(6)
 LIGHT_POINT, LIGHT_RECT = range(2)
 MODE_PRIMARY_ID, MODE_RENDER = 0, 1
+FRAME_STATS = 1
 
 
 class Transform(C.Structure):
@@ -125,7 +126,7 @@ class SceneDesc(C.Structure):
 
 class Frame(C.Structure):
     _fields_ = [("mode", i32), ("seed", u32), ("bucket_first", i32), ("bucket_stride", i32),
-                ("spp_chunk", i32), ("_pad", i32)]
+                ("spp_chunk", i32), ("flags", i32)]
 
 
 class Stats(C.Structure):

@@ -1,0 +1,590 @@
+// C ABI, device side: scene upload, frame set-up (Camera::beginFrame), kernel launches, timing.
+// Stands behind render() of the reference (src/main.cpp:373-405).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "capi_common.h"
+#include "kernels.hpp"
+
+namespace {
+
+using frayhip_detail::set_error;
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                         \
+            return FRAYHIP_E_NODEVICE;                                                            \
+        }                                                                                         \
+    } while (0)
+
+// One device allocation holding every read-only table of a scene.
+struct Arena {
+    std::vector<unsigned char> host;
+    size_t add(const void* p, size_t bytes, size_t align = 256)
+    {
+        size_t off = (host.size() + align - 1) / align * align;
+        host.resize(off + bytes);
+        if (bytes) memcpy(host.data() + off, p, bytes);
+        return off;
+    }
+};
+
+void put3(double* o, const double* p) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+void putX(DXform& X, const frayhip_transform& T)
+{
+    put3(X.off, T.offset);
+    memcpy(X.m, T.m, sizeof X.m);
+    memcpy(X.inv, T.invM, sizeof X.inv);
+}
+
+}  // namespace
+
+struct frayhip_scene {
+    void* d_arena = nullptr;
+    size_t arena_bytes = 0;
+    DScene S{};
+    frayhip_camera camera{};
+    frayhip_settings settings{};
+    bool whittedNeedsRecursion = false;
+    // per-frame workspace, grown on demand and kept between frames
+    void* d_work = nullptr;
+    size_t work_bytes = 0;
+    DStats* d_stats = nullptr;
+    uint32_t* d_qcount = nullptr;     // [64] queue sizes per bounce
+    hipEvent_t evA = nullptr, evB = nullptr;
+    std::vector<hipEvent_t> evPool;
+};
+
+namespace {
+
+// Camera::beginFrame, camera.cpp:34-57 (host, FP64; sin/cos/tan from the host libm like the reference).
+void matmul3(const double* a, const double* b, double* c)
+{
+    for (int i = 0; i < 9; i++) c[i] = 0.0;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            for (int k = 0; k < 3; k++) c[i * 3 + j] += a[i * 3 + k] * b[k * 3 + j];
+}
+void rowmul(const double* v, const double* m, double* o)
+{
+    for (int j = 0; j < 3; j++) o[j] = v[0] * m[j] + v[1] * m[3 + j] + v[2] * m[6 + j];
+}
+DCamera camera_begin_frame(const frayhip_camera& c, int W, int H)
+{
+    const double PI = 3.141592653589793238;
+    auto rad = [&](double a) { return a / 180.0 * PI; };
+    DCamera f{};
+    const double aspect = c.aspectRatio;
+    const double bc[3] = {-aspect - 0.0, 1.0 - 0.0, 1.0 - 1.0};
+    const double lenBC = sqrt(bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]);
+    const double m = tan(rad(c.fov / 2)) / lenBC;
+    const double tl[3] = {-aspect * m, +m, 1}, tr[3] = {+aspect * m, +m, 1}, bl[3] = {-aspect * m, -m, 1};
+    double S = sin(rad(c.roll)), C = cos(rad(c.roll));
+    const double rz[9] = {C, -S, 0, S, C, 0, 0, 0, 1};
+    S = sin(rad(c.pitch)); C = cos(rad(c.pitch));
+    const double rx[9] = {1, 0, 0, 0, C, -S, 0, S, C};
+    S = sin(rad(c.yaw)); C = cos(rad(c.yaw));
+    const double ry[9] = {C, 0, S, 0, 1, 0, -S, 0, C};
+    double t[9], rot[9];
+    matmul3(rz, rx, t);
+    matmul3(t, ry, rot);
+    rowmul(tl, rot, f.topLeft);
+    rowmul(tr, rot, f.topRight);
+    rowmul(bl, rot, f.bottomLeft);
+    const double ez[3] = {0, 0, 1}, ey[3] = {0, 1, 0}, ex[3] = {1, 0, 0};
+    rowmul(ez, rot, f.frontDir);
+    rowmul(ey, rot, f.upDir);
+    rowmul(ex, rot, f.rightDir);
+    put3(f.pos, c.pos);
+    f.w = W; f.h = H;
+    f.apertureSize = 1.0 / c.fNumber;
+    f.focalPlaneDist = c.focalPlaneDist;
+    f.stereoSeparation = c.stereoSeparation;
+    memcpy(f.leftMask, c.leftMask, sizeof f.leftMask);
+    memcpy(f.rightMask, c.rightMask, sizeof f.rightMask);
+    f.dof = c.dof;
+    return f;
+}
+
+bool shader_uses_uv(const frayhip_scene_desc& d, int s, int depth = 0)
+{
+    if (s < 0 || s >= d.n_shaders || depth > 40) return false;
+    const frayhip_shader& sh = d.shaders[s];
+    auto texUV = [&](int t) { return t >= 0 && t < d.n_textures && d.textures[t].kind != FRAYHIP_TEX_FRESNEL; };
+    if (texUV(sh.texture)) return true;
+    if (sh.kind == FRAYHIP_SHADER_LAYERED)
+        for (int i = 0; i < sh.layer_count; i++) {
+            const frayhip_layer& L = d.layers[sh.layer_begin + i];
+            if (texUV(L.texture) || shader_uses_uv(d, L.shader, depth + 1)) return true;
+        }
+    return false;
+}
+
+int grid_for(size_t n)
+{
+    size_t blocks = (n + 255) / 256;
+    const size_t cap = 256 * 8;   // 256 CUs x 8 blocks of 256 threads: the chip's full wave capacity
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+int frayhip_init(int device_id)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { set_error("frayhip_init: no HIP device available"); return FRAYHIP_E_NODEVICE; }
+    if (device_id < 0 || device_id >= n) { set_error("frayhip_init: bad device id"); return FRAYHIP_E_ARG; }
+    HIP_TRY(hipSetDevice(device_id));
+    return FRAYHIP_OK;
+}
+
+int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
+{
+    if (!desc || !out) { set_error("frayhip_scene_create: null argument"); return FRAYHIP_E_ARG; }
+    if (desc->abi_version != FRAYHIP_ABI_VERSION) { set_error("frayhip_scene_create: ABI version mismatch"); return FRAYHIP_E_ARG; }
+    const frayhip_scene_desc& d = *desc;
+    // ---- what the device path implements ----
+    for (int i = 0; i < d.n_nodes; i++) {
+        int k = d.geoms[d.nodes[i].geom].kind;
+        if (k == FRAYHIP_GEOM_CUBE || k == FRAYHIP_GEOM_CSG) {
+            set_error("frayhip_scene_create: Cube / CSG geometry is not implemented on the device path yet");
+            return FRAYHIP_E_UNSUPPORTED;
+        }
+    }
+    frayhip_scene* sc = new frayhip_scene();
+    Arena A;
+    // nodes
+    std::vector<DNode> nodes(d.n_nodes);
+    for (int i = 0; i < d.n_nodes; i++) {
+        const frayhip_node& n = d.nodes[i];
+        putX(nodes[i].T, n.T);
+        nodes[i].geomKind = d.geoms[n.geom].kind;
+        nodes[i].geomIndex = d.geoms[n.geom].index;
+        nodes[i].shader = n.shader;
+        nodes[i].bumpTex = n.bump_tex;
+        int sk = d.shaders[n.shader].kind;
+        if (sk == FRAYHIP_SHADER_REFL || sk == FRAYHIP_SHADER_REFR || sk == FRAYHIP_SHADER_LAYERED) sc->whittedNeedsRecursion = true;
+    }
+    size_t oNodes = A.add(nodes.data(), nodes.size() * sizeof(DNode));
+    std::vector<DPlane> planes(d.n_planes);
+    for (int i = 0; i < d.n_planes; i++) { planes[i].limit = d.planes[i].limit; planes[i].height = d.planes[i].height; }
+    size_t oPlanes = A.add(planes.data(), planes.size() * sizeof(DPlane));
+    std::vector<DSphere> spheres(d.n_spheres);
+    for (int i = 0; i < d.n_spheres; i++) { put3(spheres[i].O, d.spheres[i].O); spheres[i].R = d.spheres[i].R; }
+    size_t oSpheres = A.add(spheres.data(), spheres.size() * sizeof(DSphere));
+    // meshes
+    std::vector<DMesh> meshes(d.n_meshes);
+    struct MeshOff { size_t tris, attrs, kd, refs; };
+    std::vector<MeshOff> moff(d.n_meshes);
+    for (int mi = 0; mi < d.n_meshes; mi++) {
+        const frayhip_mesh& m = d.meshes[mi];
+        DMesh& M = meshes[mi];
+        put3(M.bmin, m.bbox_min);
+        put3(M.bmax, m.bbox_max);
+        M.nTris = m.n_triangles;
+        M.hasKd = m.has_kd;
+        M.smooth = !(m.faceted || m.n_normals == 0);
+        M.culling = m.backfaceCulling;
+        M.hasUV = m.n_uvs != 0;
+        std::vector<DTri> tris(m.n_triangles);
+        std::vector<DTriAttr> attrs(m.n_triangles);
+        for (int t = 0; t < m.n_triangles; t++) {
+            const frayhip_triangle& T = m.triangles[t];
+            DTri& o = tris[t];
+            put3(o.g, T.gnormal);
+            put3(o.A, m.vertices + 3 * (size_t)T.v[0]);
+            put3(o.N, T.ABcrossAC);
+            put3(o.AC, T.AC);
+            put3(o.AB, T.AB);
+            o.pad = 0;
+            DTriAttr& a = attrs[t];
+            memset(&a, 0, sizeof a);
+            if (M.smooth) {
+                put3(a.nA, m.normals + 3 * (size_t)T.n[0]);
+                put3(a.nB, m.normals + 3 * (size_t)T.n[1]);
+                put3(a.nC, m.normals + 3 * (size_t)T.n[2]);
+            }
+            if (M.hasUV) {
+                const double* tA = m.uvs + 3 * (size_t)T.t[0]; const double* tB = m.uvs + 3 * (size_t)T.t[1]; const double* tC = m.uvs + 3 * (size_t)T.t[2];
+                a.tA[0] = tA[0]; a.tA[1] = tA[1]; a.tB[0] = tB[0]; a.tB[1] = tB[1]; a.tC[0] = tC[0]; a.tC[1] = tC[1];
+            }
+            put3(a.dNdx, T.dNdx);
+            put3(a.dNdy, T.dNdy);
+        }
+        // KD nodes: add each node's own box extent along its split axis.  Boxes are derived
+        // top-down exactly as BBox::split does (copy parent, overwrite one coordinate).
+        std::vector<DKd> kd(m.n_kdnodes);
+        if (m.n_kdnodes > 0) {
+            struct B { double lo[3], hi[3]; };
+            std::vector<B> boxes(m.n_kdnodes);
+            for (int k = 0; k < 3; k++) { boxes[0].lo[k] = m.bbox_min[k]; boxes[0].hi[k] = m.bbox_max[k]; }
+            for (int n = 0; n < m.n_kdnodes; n++) {   // parents precede children in the array
+                const frayhip_kdnode& K = m.kdnodes[n];
+                DKd& o = kd[n];
+                o.split = K.split; o.child0 = K.child0; o.parent = K.parent; o.axis = K.axis;
+                o.triBegin = K.tri_begin; o.triCount = K.tri_count; o.pad = 0;
+                o.lo = o.hi = 0;
+                if (K.axis != 3) {
+                    o.lo = boxes[n].lo[K.axis];
+                    o.hi = boxes[n].hi[K.axis];
+                    boxes[K.child0] = boxes[n];
+                    boxes[K.child0 + 1] = boxes[n];
+                    boxes[K.child0].hi[K.axis] = K.split;
+                    boxes[K.child0 + 1].lo[K.axis] = K.split;
+                }
+            }
+        }
+        moff[mi].tris = A.add(tris.data(), tris.size() * sizeof(DTri));
+        moff[mi].attrs = A.add(attrs.data(), attrs.size() * sizeof(DTriAttr));
+        moff[mi].kd = A.add(kd.data(), kd.size() * sizeof(DKd));
+        moff[mi].refs = A.add(m.trirefs, (size_t)m.n_trirefs * sizeof(int32_t));
+    }
+    size_t oTexels = A.add(d.texels, (size_t)d.n_texels * sizeof(float));
+    std::vector<DTexture> tex(d.n_textures);
+    for (int i = 0; i < d.n_textures; i++) {
+        const frayhip_texture& t = d.textures[i];
+        DTexture& o = tex[i];
+        o.kind = t.kind; o.width = t.width; o.height = t.height; o.pad = 0;
+        memcpy(o.color1, t.color1, sizeof o.color1);
+        memcpy(o.color2, t.color2, sizeof o.color2);
+        o.scaling = t.scaling; o.bumpIntensity = t.bumpIntensity; o.ior = t.ior;
+        o.texels = nullptr;   // patched below
+    }
+    std::vector<DShader> shaders(d.n_shaders);
+    for (int i = 0; i < d.n_shaders; i++) {
+        const frayhip_shader& s = d.shaders[i];
+        DShader& o = shaders[i];
+        o.kind = s.kind; o.texture = s.texture;
+        memcpy(o.color, s.color, sizeof o.color);
+        memcpy(o.specularColor, s.specularColor, sizeof o.specularColor);
+        memcpy(o.mult, s.mult, sizeof o.mult);
+        o.numSamples = s.numSamples;
+        o.exponent = s.exponent; o.specularMultiplier = s.specularMultiplier; o.glossiness = s.glossiness;
+        o.deflectionScaling = s.deflectionScaling; o.ior = s.ior;
+        o.layerBegin = s.layer_begin; o.layerCount = s.layer_count;
+        o.usesUV = shader_uses_uv(d, i);
+        o.pad = 0;
+    }
+    size_t oShaders = A.add(shaders.data(), shaders.size() * sizeof(DShader));
+    std::vector<DLayer> layers(d.n_layers);
+    for (int i = 0; i < d.n_layers; i++) {
+        layers[i].shader = d.layers[i].shader; layers[i].texture = d.layers[i].texture;
+        memcpy(layers[i].opacity, d.layers[i].opacity, sizeof layers[i].opacity);
+        layers[i].pad = 0;
+    }
+    size_t oLayers = A.add(layers.data(), layers.size() * sizeof(DLayer));
+    std::vector<DLight> lights(d.n_lights);
+    for (int i = 0; i < d.n_lights; i++) {
+        const frayhip_light& l = d.lights[i];
+        DLight& o = lights[i];
+        o.kind = l.kind; o.xSubd = l.xSubd; o.ySubd = l.ySubd; o.pad = 0;
+        memcpy(o.color, l.color, sizeof o.color);
+        o.power = l.power;
+        put3(o.pos, l.pos);
+        putX(o.T, l.T);
+        put3(o.center, l.center);
+        o.area = l.area;
+    }
+    size_t oLights = A.add(lights.data(), lights.size() * sizeof(DLight));
+    size_t oMeshes = A.add(nullptr, 0);              // reserve aligned slots for the tables that hold device pointers
+    A.host.resize(oMeshes + meshes.size() * sizeof(DMesh));
+    size_t oTex = A.add(nullptr, 0);
+    A.host.resize(oTex + tex.size() * sizeof(DTexture));
+
+    if (hipMalloc(&sc->d_arena, A.host.size() ? A.host.size() : 256) != hipSuccess) {
+        set_error("frayhip_scene_create: hipMalloc failed (no device?)");
+        delete sc;
+        return FRAYHIP_E_NODEVICE;
+    }
+    unsigned char* base = (unsigned char*)sc->d_arena;
+    for (int mi = 0; mi < d.n_meshes; mi++) {
+        meshes[mi].tris = (const DTri*)(base + moff[mi].tris);
+        meshes[mi].attrs = (const DTriAttr*)(base + moff[mi].attrs);
+        meshes[mi].kd = (const DKd*)(base + moff[mi].kd);
+        meshes[mi].refs = (const int32_t*)(base + moff[mi].refs);
+    }
+    if (!meshes.empty()) memcpy(A.host.data() + oMeshes, meshes.data(), meshes.size() * sizeof(DMesh));
+    for (int i = 0; i < d.n_textures; i++) tex[i].texels = (const float*)(base + oTexels) + d.textures[i].texel_offset;
+    if (!tex.empty()) memcpy(A.host.data() + oTex, tex.data(), tex.size() * sizeof(DTexture));
+    hipError_t e = hipMemcpy(sc->d_arena, A.host.data(), A.host.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_error(std::string("frayhip_scene_create: upload failed: ") + hipGetErrorString(e)); hipFree(sc->d_arena); delete sc; return FRAYHIP_E_NODEVICE; }
+    sc->arena_bytes = A.host.size();
+
+    DScene& S = sc->S;
+    S.nodes = (const DNode*)(base + oNodes);
+    S.planes = (const DPlane*)(base + oPlanes);
+    S.spheres = (const DSphere*)(base + oSpheres);
+    S.meshes = (const DMesh*)(base + oMeshes);
+    S.shaders = (const DShader*)(base + oShaders);
+    S.layers = (const DLayer*)(base + oLayers);
+    S.textures = (const DTexture*)(base + oTex);
+    S.lights = (const DLight*)(base + oLights);
+    S.env.present = d.environment.present;
+    S.env.loaded = d.environment.loaded;
+    for (int f = 0; f < 6; f++) {
+        S.env.width[f] = d.environment.width[f];
+        S.env.height[f] = d.environment.height[f];
+        S.env.face[f] = (const float*)(base + oTexels) + d.environment.texel_offset[f];
+    }
+    S.nNodes = d.n_nodes;
+    S.nLights = d.n_lights;
+    sc->camera = d.camera;
+    sc->settings = d.settings;
+    hipMalloc((void**)&sc->d_stats, sizeof(DStats));
+    hipMalloc((void**)&sc->d_qcount, 64 * sizeof(uint32_t));
+    hipEventCreate(&sc->evA);
+    hipEventCreate(&sc->evB);
+    *out = sc;
+    return FRAYHIP_OK;
+}
+
+void frayhip_scene_destroy(frayhip_scene* s)
+{
+    if (!s) return;
+    if (s->d_arena) hipFree(s->d_arena);
+    if (s->d_work) hipFree(s->d_work);
+    if (s->d_stats) hipFree(s->d_stats);
+    if (s->d_qcount) hipFree(s->d_qcount);
+    if (s->evA) hipEventDestroy(s->evA);
+    if (s->evB) hipEventDestroy(s->evB);
+    for (auto e : s->evPool) hipEventDestroy(e);
+    delete s;
+}
+
+}  // extern "C"
+
+namespace {
+
+int ensure_work(frayhip_scene* sc, size_t bytes)
+{
+    if (sc->work_bytes >= bytes) return FRAYHIP_OK;
+    if (sc->d_work) hipFree(sc->d_work);
+    sc->d_work = nullptr;
+    sc->work_bytes = 0;
+    if (hipMalloc(&sc->d_work, bytes) != hipSuccess) { set_error("frayhip_render: out of device memory for the path queues"); return FRAYHIP_E_NOMEM; }
+    sc->work_bytes = bytes;
+    return FRAYHIP_OK;
+}
+
+// Carves the SoA path-queue arrays out of the workspace.
+unsigned char* carve_queue(unsigned char* p, size_t n, PathQueue& Q)
+{
+    auto take = [&](size_t bytes) { unsigned char* r = p; p += (bytes + 255) / 256 * 256; return r; };
+    Q.ox = (double*)take(n * 8); Q.oy = (double*)take(n * 8); Q.oz = (double*)take(n * 8);
+    Q.dx = (double*)take(n * 8); Q.dy = (double*)take(n * 8); Q.dz = (double*)take(n * 8);
+    Q.tr = (float*)take(n * 4); Q.tg = (float*)take(n * 4); Q.tb = (float*)take(n * 4);
+    Q.ar = (float*)take(n * 4); Q.ag = (float*)take(n * 4); Q.ab = (float*)take(n * 4);
+    Q.slot = (uint32_t*)take(n * 4); Q.depthFlags = (uint32_t*)take(n * 4);
+    Q.rndJ = (uint32_t*)take(n * 4); Q.rndA = (uint32_t*)take(n * 4); Q.rndB = (uint32_t*)take(n * 4);
+    Q.tabJ = (uint32_t*)take(n * 4); Q.tabA = (uint32_t*)take(n * 4); Q.tabB = (uint32_t*)take(n * 4);
+    return p;
+}
+size_t queue_bytes(size_t n)
+{
+    auto r = [](size_t b) { return (b + 255) / 256 * 256; };
+    return 6 * r(n * 8) + 14 * r(n * 4);
+}
+
+hipEvent_t pool_event(frayhip_scene* sc, size_t i)
+{
+    while (sc->evPool.size() <= i) { hipEvent_t e; hipEventCreate(&e); sc->evPool.push_back(e); }
+    return sc->evPool[i];
+}
+
+template <bool ST>
+int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t* d_id, double* d_dist, hipStream_t stream, frayhip_stats* st)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const frayhip_settings& set = sc->settings;
+    const int W = set.frameWidth, H = set.frameHeight;
+    DFrame F{};
+    F.W = W; F.H = H;
+    F.BW = (W - 1) / 48 + 1; F.BH = (H - 1) / 48 + 1;
+    F.bucketStride = f->bucket_stride > 0 ? f->bucket_stride : 1;
+    F.bucketFirst = f->bucket_first;
+    F.nBuckets = frayhip_bucket_count(W, H, F.bucketFirst, F.bucketStride);
+    if (F.nBuckets < 0) { set_error("frayhip_render: bad bucket_first / bucket_stride"); return FRAYHIP_E_ARG; }
+    int spp = set.wantAA ? 5 : 1;                                   // main.cpp:395-400
+    if (sc->camera.dof) spp = std::max(spp, sc->camera.numDOFSamples);
+    if (set.gi) spp = std::max(spp, set.numPaths);
+    F.spp = spp;
+    F.seed = f->seed;
+    F.jitter = (sc->camera.dof || set.gi) ? 1 : 0;
+    const int nItems = F.nBuckets * 2304;
+    DScene S = sc->S;
+    S.ambient[0] = set.ambientLight[0]; S.ambient[1] = set.ambientLight[1]; S.ambient[2] = set.ambientLight[2];
+    S.maxTraceDepth = set.maxTraceDepth;
+    S.gi = set.gi;
+    S.saturation = set.saturation;
+    DCamera C = camera_begin_frame(sc->camera, W, H);
+
+    HIP_TRY(hipMemsetAsync(sc->d_stats, 0, sizeof(DStats), stream));
+    HIP_TRY(hipEventRecord(sc->evA, stream));
+    size_t nTraceEvents = 0;
+    double algBytes = 0;
+
+    if (f->mode == FRAYHIP_MODE_PRIMARY_ID) {
+        if (nItems > 0) {
+            hipEvent_t a = pool_event(sc, 0), b = pool_event(sc, 1);
+            HIP_TRY(hipEventRecord(a, stream));
+            hipLaunchKernelGGL(k_primary<ST>, dim3(grid_for(nItems)), dim3(256), 0, stream, S, C, F, nItems, d_id, d_dist, sc->d_stats);
+            HIP_TRY(hipEventRecord(b, stream));
+            nTraceEvents = 2;
+        }
+    } else if (f->mode == FRAYHIP_MODE_RENDER) {
+        if (!d_rgb) { set_error("frayhip_render: MODE_RENDER needs an rgb buffer"); return FRAYHIP_E_ARG; }
+        if (sc->camera.stereoSeparation > 0) { set_error("frayhip_render: stereo cameras are not implemented on the device path yet"); return FRAYHIP_E_UNSUPPORTED; }
+        if (!set.gi) {
+            if (sc->whittedNeedsRecursion) { set_error("frayhip_render: Whitted recursion (Refl / Refr / Layered) is not implemented on the device path yet"); return FRAYHIP_E_UNSUPPORTED; }
+            if (!F.jitter && spp > 5) { set_error("frayhip_render: bad sample count"); return FRAYHIP_E_ARG; }
+            if (nItems > 0) {
+                hipEvent_t a = pool_event(sc, 0), b = pool_event(sc, 1);
+                HIP_TRY(hipEventRecord(a, stream));
+                hipLaunchKernelGGL(k_whitted<ST>, dim3(grid_for(nItems)), dim3(256), 0, stream, S, C, F, nItems, d_rgb, sc->d_stats);
+                HIP_TRY(hipEventRecord(b, stream));
+                nTraceEvents = 2;
+            }
+        } else if (nItems > 0) {
+            if (set.maxTraceDepth > 60) { set_error("frayhip_render: maxTraceDepth above 60 is not supported"); return FRAYHIP_E_UNSUPPORTED; }
+            int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, ((size_t)1 << 26) / (size_t)nItems);
+            if (chunk > spp) chunk = spp;
+            const size_t nPaths = (size_t)nItems * chunk;
+            const size_t need = 2 * queue_bytes(nPaths) + nPaths * 12 + (size_t)nItems * 12 + 4096;
+            int rc = ensure_work(sc, need);
+            if (rc) return rc;
+            PathQueue Q[2];
+            unsigned char* p = (unsigned char*)sc->d_work;
+            p = carve_queue(p, nPaths, Q[0]);
+            p = carve_queue(p, nPaths, Q[1]);
+            float* sampleRad = (float*)p; p += (nPaths * 12 + 255) / 256 * 256;
+            float* sum = (float*)p;
+            const int nBounce = set.maxTraceDepth + 2;
+            for (int s0 = 0; s0 < spp; s0 += chunk) {
+                const int cn = std::min(chunk, spp - s0);
+                HIP_TRY(hipMemsetAsync(sc->d_qcount, 0, 64 * sizeof(uint32_t), stream));
+                hipLaunchKernelGGL(k_pt_init<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, C, F, nItems, s0, cn, Q[0],
+                                   sc->d_qcount, sampleRad, sc->d_stats);
+                for (int b = 0; b < nBounce; b++) {
+                    hipEvent_t ea = pool_event(sc, nTraceEvents), eb = pool_event(sc, nTraceEvents + 1);
+                    HIP_TRY(hipEventRecord(ea, stream));
+                    hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, Q[b & 1], Q[(b + 1) & 1],
+                                       sc->d_qcount + b, sc->d_qcount + b + 1, sampleRad, sc->d_stats);
+                    HIP_TRY(hipEventRecord(eb, stream));
+                    nTraceEvents += 2;
+                }
+                hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, stream, F, nItems, s0, cn, sampleRad, sum, d_rgb);
+            }
+        }
+    } else {
+        set_error("frayhip_render: unknown mode");
+        return FRAYHIP_E_ARG;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sc->evB, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    DStats ds;
+    HIP_TRY(hipMemcpy(&ds, sc->d_stats, sizeof ds, hipMemcpyDeviceToHost));
+    if (ds.rngOverflow) {
+        set_error("frayhip_render: a camera sample drew more than 227 random words; the register-resident mt19937 cannot follow the reference there");
+        return FRAYHIP_E_UNSUPPORTED;
+    }
+    if (st) {
+        frayhip_stats o{};
+        o.closest_rays = ds.closest; o.shadow_rays = ds.shadow; o.node_tests = ds.node; o.kd_inner_visits = ds.kdInner;
+        o.leaf_refs = ds.leafRefs; o.tri_tests = ds.tri; o.prim_tests = ds.prim; o.smooth_hits = ds.smooth;
+        o.samples = ds.samples; o.texture_fetches = ds.tex;
+        float ms = 0;
+        hipEventElapsedTime(&ms, sc->evA, sc->evB);
+        o.ms_kernels = ms;
+        double tr = 0;
+        for (size_t i = 0; i + 1 < nTraceEvents; i += 2) {
+            float m2 = 0;
+            hipEventElapsedTime(&m2, sc->evPool[i], sc->evPool[i + 1]);
+            tr += m2;
+        }
+        o.ms_trace = tr;
+        o.trace_launches = nTraceEvents / 2;
+        // SURVEY 8(d) byte model, evaluated from the counters (zero unless FRAYHIP_FRAME_STATS)
+        algBytes = 88.0 * (double)ds.closest + 73.0 * (double)ds.shadow + 168.0 * (double)ds.node + 16.0 * (double)ds.kdInner +
+                   4.0 * (double)ds.leafRefs + 120.0 * (double)ds.tri + 32.0 * (double)ds.prim + 144.0 * (double)ds.smooth +
+                   12.0 * (double)ds.tex;
+        o.alg_bytes_trace = algBytes;
+        o.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        *st = o;
+    }
+    return FRAYHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int frayhip_render_device(frayhip_scene* s, const frayhip_frame* f, float* d_rgb, int32_t* d_hit_id, double* d_hit_dist, void* hip_stream,
+                          frayhip_stats* st)
+{
+    if (!s || !f) { set_error("frayhip_render_device: null argument"); return FRAYHIP_E_ARG; }
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (f->flags & FRAYHIP_FRAME_STATS) return render_impl<true>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st);
+    return render_impl<false>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st);
+}
+
+int frayhip_render(frayhip_scene* s, const frayhip_frame* f, float* rgb, int32_t* hit_id, double* hit_dist, frayhip_stats* st)
+{
+    if (!s || !f) { set_error("frayhip_render: null argument"); return FRAYHIP_E_ARG; }
+    const size_t n = (size_t)s->settings.frameWidth * s->settings.frameHeight;
+    float* d_rgb = nullptr; int32_t* d_id = nullptr; double* d_dist = nullptr;
+    int rc = FRAYHIP_OK;
+    auto cleanup = [&]() { if (d_rgb) hipFree(d_rgb); if (d_id) hipFree(d_id); if (d_dist) hipFree(d_dist); };
+    if (rgb && hipMalloc((void**)&d_rgb, n * 12) != hipSuccess) rc = FRAYHIP_E_NOMEM;
+    if (!rc && hit_id && hipMalloc((void**)&d_id, n * 4) != hipSuccess) rc = FRAYHIP_E_NOMEM;
+    if (!rc && hit_dist && hipMalloc((void**)&d_dist, n * 8) != hipSuccess) rc = FRAYHIP_E_NOMEM;
+    if (rc) { set_error("frayhip_render: hipMalloc failed"); cleanup(); return rc; }
+    // pixels outside this call's buckets keep what the caller had in the buffers
+    if (d_rgb) hipMemcpy(d_rgb, rgb, n * 12, hipMemcpyHostToDevice);
+    if (d_id) hipMemcpy(d_id, hit_id, n * 4, hipMemcpyHostToDevice);
+    if (d_dist) hipMemcpy(d_dist, hit_dist, n * 8, hipMemcpyHostToDevice);
+    rc = frayhip_render_device(s, f, d_rgb, d_id, d_dist, nullptr, st);
+    if (!rc) {
+        if (d_rgb) hipMemcpy(rgb, d_rgb, n * 12, hipMemcpyDeviceToHost);
+        if (d_id) hipMemcpy(hit_id, d_id, n * 4, hipMemcpyDeviceToHost);
+        if (d_dist) hipMemcpy(hit_dist, d_dist, n * 8, hipMemcpyDeviceToHost);
+    }
+    cleanup();
+    return rc;
+}
+
+static int pack_impl(const float* d_frame, float* d_packed, int width, int height, int channels, int first, int stride, void* hip_stream, int unpack)
+{
+    if (!d_frame || !d_packed || channels < 1) { set_error("frayhip_pack_buckets_device: bad argument"); return FRAYHIP_E_ARG; }
+    int nb = frayhip_bucket_count(width, height, first, stride);
+    if (nb < 0) { set_error("frayhip_pack_buckets_device: bad bucket range"); return FRAYHIP_E_ARG; }
+    DFrame F{};
+    F.W = width; F.H = height; F.BW = (width - 1) / 48 + 1; F.BH = (height - 1) / 48 + 1;
+    F.bucketFirst = first; F.bucketStride = stride; F.nBuckets = nb;
+    int nItems = nb * 2304;
+    if (nItems > 0) hipLaunchKernelGGL(k_pack, dim3(grid_for(nItems)), dim3(256), 0, (hipStream_t)hip_stream, F, nItems, channels, (float*)d_frame, d_packed, unpack);
+    HIP_TRY(hipGetLastError());
+    return FRAYHIP_OK;
+}
+int frayhip_pack_buckets_device(const float* d_frame, float* d_packed, int width, int height, int channels, int bucket_first, int bucket_stride, void* hip_stream)
+{
+    return pack_impl(d_frame, d_packed, width, height, channels, bucket_first, bucket_stride, hip_stream, 0);
+}
+int frayhip_unpack_buckets_device(const float* d_packed, float* d_frame, int width, int height, int channels, int bucket_first, int bucket_stride, void* hip_stream)
+{
+    return pack_impl(d_frame, (float*)d_packed, width, height, channels, bucket_first, bucket_stride, hip_stream, 1);
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// FP64 vector / FP32 colour helpers for the device code.  Operation order inside each helper is
+// the reference's (src/vector.h, src/color.h, src/matrix.h); the translation unit is compiled with
+// -ffp-contract=off so no a*b+c is fused, which is what keeps hit records bit-identical to the
+// CPU reference build.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define FD __device__ __forceinline__
+
+struct V3 { double x, y, z; };
+struct C3 { float r, g, b; };
+
+FD V3 v3(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+FD V3 ld3(const double* p) { return v3(p[0], p[1], p[2]); }
+FD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+FD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+FD V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+FD V3 operator*(V3 a, double m) { return v3(a.x * m, a.y * m, a.z * m); }
+FD V3 operator*(double m, V3 a) { return v3(a.x * m, a.y * m, a.z * m); }
+FD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+FD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+FD double lengthSqr(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+FD double length(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+FD V3 normalized(V3 a) { double m = 1.0 / length(a); return a * m; }   // vector.h:81-85
+FD double comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+FD V3 faceforward(V3 d, V3 n) { return dot(d, n) < 0 ? n : -n; }        // vector.h:169-175
+FD V3 reflect(V3 i, V3 n) { return i + 2 * dot(-i, n) * n; }            // vector.h:178-181
+FD V3 refract(V3 i, V3 n, double ior)                                   // vector.h:184-191
+{
+    double NdotI = dot(i, n);
+    double k = 1 - (ior * ior) * (1 - NdotI * NdotI);
+    if (k < 0.0) return v3(0, 0, 0);
+    return normalized(ior * i - (ior * NdotI + sqrt(k)) * n);
+}
+FD void orthonormalSystem(V3 a, V3& b, V3& c)                           // vector.h:197-213
+{
+    V3 t = v3(1, 0, 0);
+    if (fabs(dot(t, a)) > 0.9) t = v3(0, 1, 0);
+    b = normalized(cross(a, t));
+    c = cross(a, b);
+}
+// v * M, row-vector convention (matrix.h:36-45); m is row-major 3x3.
+FD V3 mulM(V3 v, const double* m)
+{
+    return v3(v.x * m[0] + v.y * m[3] + v.z * m[6], v.x * m[1] + v.y * m[4] + v.z * m[7],
+              v.x * m[2] + v.y * m[5] + v.z * m[8]);
+}
+
+FD C3 c3(float r, float g, float b) { C3 c; c.r = r; c.g = g; c.b = b; return c; }
+FD C3 ldc(const float* p) { return c3(p[0], p[1], p[2]); }
+FD C3 operator+(C3 a, C3 b) { return c3(a.r + b.r, a.g + b.g, a.b + b.b); }
+FD C3 operator-(C3 a, C3 b) { return c3(a.r - b.r, a.g - b.g, a.b - b.b); }
+FD C3 operator*(C3 a, C3 b) { return c3(a.r * b.r, a.g * b.g, a.b * b.b); }
+FD C3 operator*(C3 a, float m) { return c3(a.r * m, a.g * m, a.b * m); }
+FD C3 operator/(C3 a, float d) { return c3(a.r / d, a.g / d, a.b / d); }     // true divide per channel (color.h:165-168)
+FD float intensity(C3 a) { return (a.r + a.g + a.b) / 3; }                  // color.h:79-82
+
+#define FRAY_PI 3.141592653589793238   // constants.h:31

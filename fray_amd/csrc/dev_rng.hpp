@@ -1,0 +1,111 @@
+// Device restatement of the reference's random numbers: std::mt19937 driven through libstdc++ 11's
+// uniform_real_distribution<float/double> and uniform_int_distribution<int>
+// (src/random_generator.cpp:41-80; /usr/include/c++/11/bits/random.tcc:3346-3380,
+// bits/uniform_int_dist.h:243-318 -- third-party arithmetic the reference does not vendor).
+//
+// Under the RNG contract every camera sample starts from a freshly seeded
+// generator and draws at most ~110 words, so only the first 227 outputs of mt19937 are ever
+// needed.  Output j (j < 227) of the first twist depends only on the seeding recurrence
+//     x[0] = seed,  x[i] = 1812433253 * (x[i-1] ^ (x[i-1] >> 30)) + i
+// at i = j, j+1 and j+397, so a stream is three registers {j, x[j], x[j+397]} and no 2.5 KB
+// state array.  Drawing more than 227 words is reported through DStats.rngOverflow (the render
+// call then fails instead of returning numbers that differ from the reference).
+#pragma once
+#include "dev_math.hpp"
+
+struct Mt { uint32_t j, a, b; };
+
+FD uint32_t mt_lcg(uint32_t x, uint32_t i) { return 1812433253u * (x ^ (x >> 30)) + i; }
+
+FD Mt mt_seed(uint32_t s)
+{
+    Mt r;
+    r.j = 0;
+    r.a = s;
+    uint32_t b = s;
+    for (uint32_t i = 1; i <= 397; i++) b = mt_lcg(b, i);
+    r.b = b;
+    return r;
+}
+
+FD uint32_t mt_next(Mt& r)
+{
+    uint32_t a1 = mt_lcg(r.a, r.j + 1);
+    uint32_t y = (r.a & 0x80000000u) | (a1 & 0x7fffffffu);
+    uint32_t v = r.b ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    r.a = a1;
+    r.b = mt_lcg(r.b, r.j + 398);
+    r.j++;
+    v ^= v >> 11;
+    v ^= (v << 7) & 0x9d2c5680u;
+    v ^= (v << 15) & 0xefc60000u;
+    v ^= v >> 18;
+    return v;
+}
+
+FD void mt_skip(Mt& r, int n)   // draws whose values the reference discards
+{
+    for (int i = 0; i < n; i++) {
+        r.a = mt_lcg(r.a, r.j + 1);
+        r.b = mt_lcg(r.b, r.j + 398);
+        r.j++;
+    }
+}
+
+// Random::randfloat: generate_canonical<float, 24> -- one word, float(u) / 2^32, clamped below 1.
+FD float rng_float(Mt& r)
+{
+    float f = (float)mt_next(r);
+    f = f / 4294967296.0f;
+    if (f >= 1.0f) f = 0x1.fffffep-1f;   // nextafter(1.0f, 0.0f)
+    return f;
+}
+
+// Random::randdouble: generate_canonical<double, 53> -- two words, (u0 + u1 * 2^32) / 2^64.
+FD double rng_double(Mt& r)
+{
+    double sum = (double)mt_next(r);
+    sum = sum + (double)mt_next(r) * 4294967296.0;
+    double v = sum / 18446744073709551616.0;
+    if (v >= 1.0) v = 0x1.fffffffffffffp-1;   // nextafter(1.0, 0.0)
+    return v;
+}
+
+// Random::randint(0, hi): Lemire's nearly divisionless method on a 32-bit generator
+// (uniform_int_distribution::_S_nd<uint64_t>).
+FD int rng_int0(Mt& r, int hi)
+{
+    uint32_t range = (uint32_t)hi + 1u;
+    uint64_t product = (uint64_t)mt_next(r) * (uint64_t)range;
+    uint32_t low = (uint32_t)product;
+    if (low < range) {
+        uint32_t threshold = (0u - range) % range;
+        while (low < threshold) {
+            product = (uint64_t)mt_next(r) * (uint64_t)range;
+            low = (uint32_t)product;
+        }
+    }
+    return (int)(product >> 32);
+}
+
+// Random::unitDiscSample, random_generator.cpp:71-80
+FD void rng_unit_disc(Mt& r, double& x, double& y)
+{
+    double angle = rng_double(r) * 2 * FRAY_PI;
+    double rad = sqrt(rng_double(r));
+    x = sin(angle) * rad;
+    y = cos(angle) * rad;
+}
+
+// Per-(pixel, sample) seed of the RNG contract; the oracle applies the same function
+// (oracle/fray_oracle.cpp sample_seed).
+FD uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+FD uint32_t sample_seed(uint32_t seed, uint32_t pixel, uint32_t sample)
+{
+    uint32_t h = fmix32(seed ^ (pixel * 0x9e3779b1u));
+    return fmix32(h ^ (sample * 0x85ebca77u) ^ 0x27d4eb2fu);
+}

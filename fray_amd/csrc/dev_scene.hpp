@@ -1,0 +1,127 @@
+// Device-side scene layout (gfx950).  Built once per scene by upload.cpp-side code in capi.hip
+// from frayhip_scene_desc; everything lives in one HBM arena and is read-only during a frame.
+//
+// Layout choices (DESIGN.md "Data layout in HBM"):
+//  * per-triangle test record = exactly the 15 doubles Triangle::intersectFast + the culling test
+//    read (gnormal, A, ABxAC, AC, AB: SURVEY 8(a) a9), padded to 128 B so a lane fetches it with
+//    eight aligned 16-byte loads; shading attributes (pre-gathered corner normals / uvs, dNdx,
+//    dNdy) live in a separate array touched only for the winning triangle;
+//  * KD nodes are 48-byte records {split, lo, hi, child0, parent, axis, leaf range}: lo/hi are the
+//    node's own box extent along its split axis, which is what a stackless walk needs to restore
+//    the box when it climbs (the reference recomputes child boxes by BBox::split on the way down,
+//    mesh.cpp:373-376, and gets the parent box back from its call stack);
+//  * nodes / lights / shaders / textures are tiny tables indexed wave-uniformly, so they are
+//    fetched through the scalar cache.
+#pragma once
+#include <stdint.h>
+
+struct DXform { double off[3]; double m[9]; double inv[9]; };
+
+struct DNode {
+    DXform T;
+    int32_t geomKind, geomIndex, shader, bumpTex;
+};
+
+struct DPlane { double limit, height; };
+struct DSphere { double O[3]; double R; };
+
+struct DTri {          // 128 B
+    double g[3];       // gnormal
+    double A[3];       // vertex A
+    double N[3];       // AB x AC
+    double AC[3];
+    double AB[3];
+    double pad;
+};
+
+struct DTriAttr {      // 168 B, winning triangle only
+    double nA[3], nB[3], nC[3];
+    double tA[2], tB[2], tC[2];
+    double dNdx[3], dNdy[3];
+};
+
+struct DKd {           // 48 B
+    double split, lo, hi;
+    int32_t child0, parent, axis, triBegin, triCount, pad;
+};
+
+struct DMesh {
+    double bmin[3], bmax[3];
+    const DTri* tris;
+    const DTriAttr* attrs;
+    const DKd* kd;
+    const int32_t* refs;
+    int32_t nTris, hasKd, smooth, culling, hasUV, pad;
+};
+
+struct DTexture {
+    int32_t kind, width, height, pad;
+    float color1[3], color2[3];
+    double scaling, bumpIntensity, ior;
+    const float* texels;
+};
+
+struct DShader {
+    int32_t kind, texture;
+    float color[3], specularColor[3], mult[3];
+    int32_t numSamples;
+    double exponent, specularMultiplier, glossiness, deflectionScaling, ior;
+    int32_t layerBegin, layerCount;
+    int32_t usesUV, pad;   // some texture in this shader (or its layers) reads info.u / info.v
+};
+
+struct DLayer { int32_t shader, texture; float opacity[3]; int32_t pad; };
+
+struct DLight {
+    int32_t kind, xSubd, ySubd, pad;
+    float color[3], power;
+    double pos[3];
+    DXform T;
+    double center[3];
+    double area;
+};
+
+struct DEnv {
+    int32_t present, loaded;
+    int32_t width[6], height[6];
+    const float* face[6];
+};
+
+// Per-frame camera state, Camera::beginFrame (camera.cpp:34-57), computed on the host.
+struct DCamera {
+    double topLeft[3], topRight[3], bottomLeft[3];
+    double frontDir[3], upDir[3], rightDir[3], pos[3];
+    double w, h, apertureSize, focalPlaneDist, stereoSeparation;
+    float leftMask[3], rightMask[3];
+    int32_t dof, pad;
+};
+
+struct DScene {
+    const DNode* nodes;
+    const DPlane* planes;
+    const DSphere* spheres;
+    const DMesh* meshes;
+    const DShader* shaders;
+    const DLayer* layers;
+    const DTexture* textures;
+    const DLight* lights;
+    DEnv env;
+    int32_t nNodes, nLights;
+    float ambient[3];
+    int32_t maxTraceDepth, gi;
+    float saturation;
+};
+
+// Work decomposition of a frame: the reference's 48x48 buckets (sdl.cpp:243-262), of which this
+// rank owns b = first + k*stride.  Work item `i` of a frame maps to bucket k = i / 2304.
+struct DFrame {
+    int32_t W, H, BW, BH;
+    int32_t bucketFirst, bucketStride, nBuckets /* owned */, spp;
+    uint32_t seed;
+    int32_t jitter;     // dof || gi: pixel offsets come from the RNG (main.cpp:351-357)
+};
+
+// Device counters mirroring frayhip_stats (only maintained by the *_stats kernel variants).
+struct DStats {
+    unsigned long long closest, shadow, node, kdInner, leafRefs, tri, prim, smooth, samples, tex, rngOverflow;
+};

@@ -1,0 +1,329 @@
+// Shading on the device: hit-attribute reconstruction, textures and bump mapping, light sampling,
+// the Whitted direct-lighting evaluators (Lambert / Phong), the BRDF eval / spawnRay pairs of the
+// path tracer and next-event estimation.  Precision follows the reference: FP64 geometry, FP32
+// colour, with its float<->double conversions kept where it has them.
+#pragma once
+#include "dev_math.hpp"
+#include "dev_rng.hpp"
+#include "dev_scene.hpp"
+#include "dev_trace.hpp"
+
+enum { RF_DIFFUSE = 2 };   // vector.h:215-219
+
+struct HitInfo {           // IntersectionInfo, geometry.h:33-39 (after Node::intersect)
+    V3 ip, norm, dNdx, dNdy;
+    double u, v;
+};
+
+// Rebuilds what Node::intersect + <Geometry>::intersect leave in `info` for the winning node
+// (geometry.cpp:30-83, 196-208; mesh.cpp:112-137).  needUV gates the sphere's atan2/asin, whose
+// result only textures and bump maps read.
+FD void finalize_hit(const DScene& S, const HitRec& h, V3 o, V3 d, bool needUV, HitInfo& info)
+{
+    const DNode& N = S.nodes[h.node];
+    V3 ls = mulM(o - ld3(N.T.off), N.T.inv);
+    V3 ldir = normalized(mulM(d, N.T.inv));
+    V3 ipl = ls + ldir * h.t;
+    V3 nl;
+    info.dNdx = v3(0, 0, 0);
+    info.dNdy = v3(0, 0, 0);
+    info.u = 0; info.v = 0;
+    if (N.geomKind == 0) {
+        nl = v3(0, 1, 0);
+        info.u = ipl.x;
+        info.v = ipl.z;
+    } else if (N.geomKind == 1) {
+        const DSphere& Sp = S.spheres[N.geomIndex];
+        nl = normalized(ipl - ld3(Sp.O));
+        if (needUV) {
+            info.u = ((atan2(nl.z, nl.x) / FRAY_PI * 180.0) + 180.0) / 360.0;
+            info.v = 1 - ((asin(nl.y) / FRAY_PI * 180.0) + 90) / 180.0;
+        }
+    } else {
+        const DMesh& M = S.meshes[N.geomIndex];
+        const DTriAttr* A = M.attrs + h.tri;
+        if (M.smooth) {
+            V3 nA = ld3(A->nA), nB = ld3(A->nB), nC = ld3(A->nC);
+            nl = normalized(nA + (nB - nA) * h.l2 + (nC - nA) * h.l3);
+        } else {
+            nl = ld3(M.tris[h.tri].g);
+        }
+        if (M.hasUV) {
+            info.u = A->tA[0] + (A->tB[0] - A->tA[0]) * h.l2 + (A->tC[0] - A->tA[0]) * h.l3;
+            info.v = A->tA[1] + (A->tB[1] - A->tA[1]) * h.l2 + (A->tC[1] - A->tA[1]) * h.l3;
+        }
+        info.dNdx = ld3(A->dNdx);
+        info.dNdy = ld3(A->dNdy);
+    }
+    info.ip = mulM(ipl, N.T.m) + ld3(N.T.off);
+    info.norm = normalized(mulM(nl, N.T.m));
+}
+
+// ---- textures -----------------------------------------------------------------------------------
+template <bool ST>
+FD C3 texel(const DTexture& T, int x, int y, Cnt& c)   // Bitmap::getPixel, bitmap.cpp:67-71
+{
+    bump<ST>(c.tex);
+    if (T.width <= 0 || x < 0 || x >= T.width || y < 0 || y >= T.height) return c3(0, 0, 0);
+    return ldc(T.texels + 3 * ((long long)x + (long long)y * T.width));
+}
+FD void wrap_texel(const DTexture& T, double u, double v, int& ix, int& iy)   // shading.cpp:149-155, 404-410
+{
+    ix = int(floor(u * T.scaling * T.width));
+    iy = int(floor(v * T.scaling * T.height));
+    ix %= T.width;
+    iy %= T.height;
+    if (ix < 0) ix += T.width;
+    if (iy < 0) iy += T.height;
+}
+FD float fresnel_schlick(V3 i, V3 n, float ior)   // shading.cpp:230-236
+{
+    float q = (1.0f - ior) / (1.0f + ior);
+    float f = (float)((double)q * (double)q);       // sqr() works in double
+    float NdotI = (float)-dot(n, i);
+    return f + (1.0f - f) * powf(1.0f - NdotI, 5.0f);
+}
+template <bool ST>
+FD C3 texture_sample(const DScene& S, int t, V3 rayDir, const HitInfo& info, Cnt& c)
+{
+    const DTexture& T = S.textures[t];
+    if (T.kind == 0) {   // CheckerTexture::sample, shading.cpp:40-46
+        int ix = int(floor(info.u * T.scaling) / 5.0);
+        int iy = int(floor(info.v * T.scaling) / 5.0);
+        return ((ix + iy) % 2 == 0) ? ldc(T.color1) : ldc(T.color2);
+    }
+    if (T.kind == 1) {   // BitmapTexture::sample, shading.cpp:147-158
+        int ix, iy;
+        wrap_texel(T, info.u, info.v, ix, iy);
+        return texel<ST>(T, ix, iy, c);
+    }
+    if (T.kind == 3) {   // FresnelTexture::sample, shading.cpp:369-385
+        V3 n;
+        double myIor;
+        if (dot(rayDir, info.norm) < 0) { n = info.norm; myIor = T.ior; }
+        else { n = -info.norm; myIor = 1.0 / T.ior; }
+        float f = fresnel_schlick(rayDir, n, (float)myIor);
+        return c3(f, f, f);
+    }
+    return c3(0, 0, 0);   // BumpTexture::sample, shading.cpp:392-395
+}
+// applyBumpMapping (main.cpp:82-90) -> BumpTexture::modifyNormal (shading.cpp:397-418)
+template <bool ST>
+FD void apply_bump(const DScene& S, int nodeIdx, HitInfo& info, Cnt& c)
+{
+    int bt = S.nodes[nodeIdx].bumpTex;
+    if (bt < 0) return;
+    const DTexture& T = S.textures[bt];
+    if (T.kind != 2) return;
+    int ix, iy;
+    wrap_texel(T, info.u, info.v, ix, iy);
+    C3 t = texel<ST>(T, ix, iy, c);
+    float dx = (float)(t.r * T.bumpIntensity);
+    float dy = (float)(t.g * T.bumpIntensity);
+    info.norm = info.norm + ((double)dx * info.dNdx + (double)dy * info.dNdy) * T.bumpIntensity;
+    info.norm = normalized(info.norm);
+}
+
+// CubemapEnvironment::getEnvironment, environment.cpp:64-98
+template <bool ST>
+FD C3 environment(const DScene& S, V3 dir, Cnt& c)
+{
+    if (!S.env.present || !S.env.loaded) return c3(0, 0, 0);
+    double maxVal = fabs(dir.x);
+    int dim = 0;
+    if (fabs(dir.y) > maxVal) { dim = 1; maxVal = fabs(dir.y); }
+    if (fabs(dir.z) > maxVal) dim = 2;
+    bool positive = comp(dir, dim) > 0;
+    V3 on = dir * (1.0 / fabs(comp(dir, dim)));
+    int face = (positive ? 3 : 0) + dim;
+    double sx, sy;
+    switch (face) {
+        case 0: sx = on.z; sy = -on.y; break;
+        case 3: sx = -on.z; sy = -on.y; break;
+        case 1: sx = on.x; sy = -on.z; break;
+        case 4: sx = on.x; sy = on.z; break;
+        case 2: sx = on.x; sy = on.y; break;
+        default: sx = on.x; sy = -on.y; break;
+    }
+    int W = S.env.width[face], H = S.env.height[face];
+    int ix = (int)(((sx + 1) / 2) * W);
+    int iy = (int)(((sy + 1) / 2) * H);
+    bump<ST>(c.tex);
+    if (ix < 0 || ix >= W || iy < 0 || iy >= H) return c3(0, 0, 0);
+    return ldc(S.env.face[face] + 3 * ((long long)ix + (long long)iy * W));
+}
+
+// ---- lights (lights.h:41-47, lights.cpp:31-77,105-108) ---------------------------------------------
+FD int light_num_samples(const DLight& L) { return L.kind == 0 ? 1 : L.xSubd * L.ySubd; }
+FD C3 light_color(const DLight& L) { return ldc(L.color) * L.power; }
+FD void light_nth_sample(const DLight& L, int idx, V3 shadePos, Mt& tab, V3& samplePos, C3& color)
+{
+    if (L.kind == 0) {
+        samplePos = ld3(L.pos);
+        color = ldc(L.color) * L.power;
+        return;
+    }
+    int column = idx % L.xSubd;
+    int row = idx / L.xSubd;
+    double areaXsize = 1.0 / L.xSubd;
+    double areaYsize = 1.0 / L.ySubd;
+    double areaXstart = column * areaXsize;
+    double areaYstart = row * areaYsize;
+    double p_x = areaXstart + areaXsize * rng_float(tab);
+    double p_y = areaYstart + areaYsize * rng_float(tab);
+    V3 pointOnLight = v3(p_x - 0.5, 0, p_y - 0.5);
+    V3 sp = mulM(shadePos - ld3(L.T.off), L.T.inv);
+    if (sp.y > 0) {
+        color = c3(0, 0, 0);
+    } else {
+        float cosWeight = float(dot(v3(0, -1, 0), sp) / length(sp));
+        color = ldc(L.color) * L.power * (float)L.area * cosWeight;
+    }
+    samplePos = mulM(pointOnLight, L.T.m) + ld3(L.T.off);
+}
+FD double light_solid_angle(const DLight& L, V3 ip)
+{
+    if (L.kind == 0) return 0;
+    double q = lengthSqr(ip - ld3(L.center));
+    return L.area / (1.0 < q ? q : 1.0);   // std::max(1.0, q)
+}
+
+// ---- Whitted: Lambert::shade / Phong::shade (shading.cpp:48-80, 101-144) ---------------------------
+template <bool ST>
+FD C3 shade_direct(const DScene& S, const DShader& sh, V3 rayDir, const HitInfo& info, Mt& tab, bool phong, Cnt& c)
+{
+    C3 diffuse = ldc(sh.color);
+    if (sh.texture >= 0) diffuse = diffuse * texture_sample<ST>(S, sh.texture, rayDir, info, c);
+    C3 result = diffuse * ldc(S.ambient);
+    const int nl = S.nLights;
+    for (int li = 0; li < nl; li++) {
+        const DLight& L = S.lights[li];
+        const int ns = light_num_samples(L);
+        C3 sum = c3(0, 0, 0);
+        for (int k = 0; k < ns; k++) {
+            C3 lc;
+            V3 lp;
+            light_nth_sample(L, k, info.ip, tab, lp, lc);
+            double lightDistSqr = lengthSqr(info.ip - lp);
+            V3 toLight = normalized(lp - info.ip);
+            V3 n = faceforward(rayDir, info.norm);
+            float cosAngle = (float)dot(toLight, n);
+            float lambertTerm = (float)(cosAngle / lightDistSqr);
+            lambertTerm = lambertTerm > 0.0f ? lambertTerm : 0.0f;   // max(0.0f, x)
+            if (visible<ST>(S, info.ip + n * 1e-6, lp, c)) {
+                C3 r = diffuse * lc * lambertTerm;
+                if (phong) {
+                    V3 fromLight = -toLight;
+                    V3 rr = reflect(fromLight, n);
+                    double cosCam = dot(-rayDir, rr);
+                    if (cosCam > 0)
+                        r = r + lc / (float)lightDistSqr * ldc(sh.specularColor) * (float)pow(cosCam, sh.exponent) * (float)sh.specularMultiplier;
+                }
+                sum = sum + r;
+            }
+        }
+        result = result + sum / (float)ns;
+    }
+    return result;
+}
+
+// ---- path tracing: BRDF::eval / BRDF::spawnRay ---------------------------------------------------------
+FD V3 hemisphere_sample(Mt& tab, V3 norm)   // main.cpp:92-116
+{
+    double u = rng_double(tab);
+    double v = rng_double(tab);
+    double theta = 2 * FRAY_PI * u;
+    double phi = acos(2 * v - 1);
+    V3 dir = v3(sin(phi) * cos(theta), cos(phi), sin(phi) * sin(theta));
+    if (dot(dir, norm) > 0) return dir;
+    return -dir;
+}
+FD C3 brdf_eval(const DShader& sh, const HitInfo& x, V3 w_out)
+{
+    if (sh.kind == 1) {   // Lambert::eval, shading.cpp:82-86
+        double dd = dot(x.norm, w_out);
+        float cosTerm = (float)(0.0 < dd ? dd : 0.0);
+        return ldc(sh.color) * (float)(cosTerm / FRAY_PI);
+    }
+    if (sh.kind == 3 || sh.kind == 4) return c3(0, 0, 0);   // Reflection / Refraction::eval
+    return c3(1, 0, 0);                                     // Shader::eval default, shading.h:124-127
+}
+// Number of table-generator words the discarded first spawnRay consumes (main.cpp:219-224).
+FD int spawn_words(const DShader& sh) { return sh.kind == 1 ? 4 : 0; }
+
+struct PathRay { V3 o, d; int depth; unsigned flags; };
+
+FD void spawn_ray(const DShader& sh, const HitInfo& x, const PathRay& w_in, Mt& tab, PathRay& w_out, C3& brdf, float& pdf)
+{
+    w_out = w_in;
+    if (sh.kind == 1) {   // Lambert::spawnRay, shading.cpp:88-99
+        w_out.depth = w_in.depth + 1;
+        w_out.o = x.ip + x.norm * 1e-6;
+        w_out.d = hemisphere_sample(tab, x.norm);
+        w_out.flags |= RF_DIFFUSE;
+        double dd = dot(x.norm, w_out.d);
+        float cosTerm = (float)(0.0 < dd ? dd : 0.0);
+        brdf = ldc(sh.color) * (float)(cosTerm / FRAY_PI);
+        pdf = (float)(1 / (2 * FRAY_PI));
+        return;
+    }
+    if (sh.kind == 3) {   // Reflection::spawnRay, shading.cpp:217-227
+        V3 n = faceforward(w_in.d, x.norm);
+        w_out.depth = w_in.depth + 1;
+        w_out.o = x.ip + n * 1e-6;
+        w_out.d = reflect(w_in.d, x.norm);
+        w_out.flags &= ~(unsigned)RF_DIFFUSE;
+        brdf = ldc(sh.mult) * 1e9f;
+        pdf = 1e9f;
+        return;
+    }
+    if (sh.kind == 4) {   // Refraction::spawnRay, shading.cpp:270-299
+        V3 n = faceforward(w_in.d, x.norm);
+        double myIor = dot(n, x.norm) > 0 ? 1.0 / sh.ior : sh.ior / 1.0;
+        V3 refr = refract(w_in.d, n, myIor);
+        if (!(refr.x == 0 && refr.y == 0 && refr.z == 0)) {
+            w_out.o = x.ip - n * 1e-6;
+            w_out.d = refr;
+            w_out.depth = w_in.depth + 1;
+            w_out.flags &= ~(unsigned)RF_DIFFUSE;
+            brdf = ldc(sh.mult) * 1e9f;
+            pdf = 1e9f;
+        } else {
+            // brdf 0, pdf 1; w_out stays as pathtrace() initialised it: the incoming ray, depth + 1
+            w_out.depth = w_in.depth + 1;
+            brdf = c3(0, 0, 0);
+            pdf = 1.0f;
+        }
+        return;
+    }
+    // Shader::spawnRay default (Const / Phong / Layered), shading.h:128-134: same ray again
+    w_out.depth = w_in.depth + 1;
+    brdf = c3(1, 0, 0);
+    pdf = 1;
+}
+
+// explicitLightSample, main.cpp:118-169.  `rnd` is the worker's local generator, `tab` the
+// per-thread table generator (RectLight::getNthSample draws from the latter).
+template <bool ST>
+FD C3 explicit_light_sample(const DScene& S, V3 rayDir, const HitInfo& info, C3 pm, const DShader& sh, Mt& rnd, Mt& tab, Cnt& c)
+{
+    if (S.nLights == 0) return c3(0, 0, 0);
+    int lightIdx = rng_int0(rnd, S.nLights - 1);
+    const DLight& L = S.lights[lightIdx];
+    V3 x = info.ip;
+    double solidAngle = light_solid_angle(L, x);
+    if (solidAngle == 0) return c3(0, 0, 0);
+    int randSample = rng_int0(rnd, light_num_samples(L) - 1);
+    V3 pointOnLight;
+    C3 unused;
+    light_nth_sample(L, randSample, x, tab, pointOnLight, unused);
+    if (!visible<ST>(S, x + info.norm * 1e-6, pointOnLight, c)) return c3(0, 0, 0);
+    C3 Le = light_color(L);
+    V3 w_out = normalized(pointOnLight - x);
+    C3 brdfAtPoint = brdf_eval(sh, info, w_out);
+    if (intensity(brdfAtPoint) == 0) return c3(0, 0, 0);
+    float probHitLightArea = (float)(1.0f / solidAngle);
+    float probPickThisLight = 1.0f / (float)S.nLights;
+    float chooseLightProb = probHitLightArea * probPickThisLight;
+    return Le * pm * brdfAtPoint / chooseLightProb;
+}

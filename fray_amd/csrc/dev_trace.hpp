@@ -1,0 +1,307 @@
+// Ray / scene intersection on the device: the closest-hit loop over nodes and lights
+// (main.cpp:178-199, 250-271), visible() (main.cpp:64-80), Node::intersect (geometry.cpp:196-208),
+// Plane / Sphere (geometry.cpp:30-83), RectLight::intersect (lights.cpp:79-103) and
+// Mesh::intersect with its KD-tree (mesh.cpp:144-165, 357-394).
+//
+// The KD walk is stackless: the reference recurses (depth reaches 65 on teapot_hires) and carries
+// the child boxes on its call stack.  Here a lane keeps the current box in registers, narrows one
+// coordinate when it goes down and restores it from the parent's {lo, hi} when it climbs; "which
+// child next" is recomputed from ray.start[axis] < split, so the visiting order, the set of box
+// tests, the triangles tested and the first accepted leaf are exactly the reference's.
+#pragma once
+#include "dev_math.hpp"
+#include "dev_scene.hpp"
+
+// Per-lane work counters (frayhip_stats); only the <true> instantiations touch them.
+struct Cnt {
+    unsigned long long closest, shadow, node, kdInner, leafRefs, tri, prim, smooth, samples, tex;
+};
+template <bool ST> FD void bump(unsigned long long& c, unsigned long long n = 1) { if (ST) c += n; }
+
+// Closest-hit record.  Shading attributes (ip, normal, uv, dNdx/dNdy) are re-derived from it for
+// the winning node only (finalize_hit in dev_shade.hpp) -- same arithmetic, so same bits.
+struct HitRec {
+    int node;       // node index; -1 miss; -2-i light i
+    int tri;        // winning triangle (meshes)
+    double dist;    // world distance (Node::intersect's recomputed dist)
+    double t;       // local ray parameter: plane `scaling`, sphere `dist`, triangle gamma
+    double l2, l3;  // barycentrics (meshes)
+};
+
+struct Box6 { double lox, loy, loz, hix, hiy, hiz; };
+
+FD bool box_inside(const Box6& b, V3 v)   // BBox::inside, bbox.h:79-84
+{
+    return b.lox - 1e-6 <= v.x && v.x <= b.hix + 1e-6 && b.loy - 1e-6 <= v.y && v.y <= b.hiy + 1e-6 &&
+           b.loz - 1e-6 <= v.z && v.z <= b.hiz + 1e-6;
+}
+
+// One dimension of BBox::testIntersect (bbox.h:89-132): 0 = keep going, 1 = hit, 2 = reject.
+FD int box_dim(double sd, double dd, double rd, double lo, double hi, double su, double du, double lou, double hiu,
+               double sv, double dv, double lov, double hiv)
+{
+    if ((dd < 0 && sd < lo) || (dd > 0 && sd > hi)) return 2;
+    if (fabs(dd) < 1e-9) return 0;
+    double dist = (lo - sd) * rd;
+    if (dist < 0) return 0;
+    double x = su + du * dist;
+    if (lou <= x && x <= hiu) {
+        double y = sv + dv * dist;
+        if (lov <= y && y <= hiv) return 1;
+    }
+    dist = (hi - sd) * rd;
+    if (dist < 0) return 0;
+    x = su + du * dist;
+    if (lou <= x && x <= hiu) {
+        double y = sv + dv * dist;
+        if (lov <= y && y <= hiv) return 1;
+    }
+    return 0;
+}
+
+FD bool box_test(const Box6& b, V3 s, V3 d, V3 rd)   // BBox::testIntersect, bbox.h:87-134
+{
+    if (box_inside(b, s)) return true;
+    int r;
+    // dim 0: u = 1 (y), v = 2 (z)
+    r = box_dim(s.x, d.x, rd.x, b.lox, b.hix, s.y, d.y, b.loy, b.hiy, s.z, d.z, b.loz, b.hiz);
+    if (r) return r == 1;
+    // dim 1: u = 0 (x), v = 2 (z)
+    r = box_dim(s.y, d.y, rd.y, b.loy, b.hiy, s.x, d.x, b.lox, b.hix, s.z, d.z, b.loz, b.hiz);
+    if (r) return r == 1;
+    // dim 2: u = 0 (x), v = 1 (y)
+    r = box_dim(s.z, d.z, rd.z, b.loz, b.hiz, s.x, d.x, b.lox, b.hix, s.y, d.y, b.loy, b.hiy);
+    return r == 1;
+}
+
+FD void box_set_hi(Box6& b, int axis, double v) { if (axis == 0) b.hix = v; else if (axis == 1) b.hiy = v; else b.hiz = v; }
+FD void box_set_lo(Box6& b, int axis, double v) { if (axis == 0) b.lox = v; else if (axis == 1) b.loy = v; else b.loz = v; }
+
+// Mesh::intersectTriangle + Triangle::intersectFast (mesh.cpp:102-141, triangle.cpp:66-94),
+// test part only.  `best` is info.dist: accepted when gamma <= best, so the LAST equal-distance
+// triangle in visiting order wins, as in the reference.
+template <bool ST>
+FD bool tri_test(const DTri* T, int culling, V3 s, V3 d, double& best, double& l2o, double& l3o, Cnt& c)
+{
+    bump<ST>(c.tri);
+    if (culling && dot(d, ld3(T->g)) > 0) return false;
+    V3 N = ld3(T->N);
+    V3 D = -d;
+    double Dcr = dot(N, D);
+    if (fabs(Dcr) < 1e-12) return false;
+    double rDcr = 1 / Dcr;
+    V3 H = s - ld3(T->A);
+    double gamma = dot(N, H) * rDcr;
+    if (gamma < 0 || gamma > best) return false;
+    double l2 = dot(cross(H, ld3(T->AC)), D) * rDcr;
+    if (l2 < 0 || l2 > 1) return false;
+    double l3 = dot(cross(ld3(T->AB), H), D) * rDcr;
+    if (l3 < 0 || l3 > 1) return false;
+    double l1 = 1 - (l2 + l3);
+    if (l1 < 0) return false;
+    best = gamma;
+    l2o = l2;
+    l3o = l3;
+    return true;
+}
+
+// Mesh::intersect (mesh.cpp:144-165).  On true: gamma / tri / l2 / l3 describe info.
+template <bool ST>
+FD bool mesh_intersect(const DMesh& M, V3 s, V3 d, double& gamma, int& tri, double& l2, double& l3, Cnt& c)
+{
+    V3 rd;   // RRay::prepareForTracing, bbox.h:49-54
+    rd.x = fabs(d.x) > 1e-12 ? 1.0 / d.x : 1e12;
+    rd.y = fabs(d.y) > 1e-12 ? 1.0 / d.y : 1e12;
+    rd.z = fabs(d.z) > 1e-12 ? 1.0 / d.z : 1e12;
+    Box6 box;
+    box.lox = M.bmin[0]; box.loy = M.bmin[1]; box.loz = M.bmin[2];
+    box.hix = M.bmax[0]; box.hiy = M.bmax[1]; box.hiz = M.bmax[2];
+    if (!box_test(box, s, d, rd)) return false;
+    gamma = 1e99;
+    const int culling = M.culling;
+    if (!M.hasKd) {
+        bool found = false;
+        const int n = M.nTris;
+        for (int i = 0; i < n; i++)
+            if (tri_test<ST>(M.tris + i, culling, s, d, gamma, l2, l3, c)) { found = true; tri = i; }
+        return found;
+    }
+    // ---- stackless KD walk (Mesh::intersectKD, mesh.cpp:357-394) ----
+    const DKd* kd = M.kd;
+    int node = 0;
+    bool down = true;          // true: entering `node`; false: leaving it upwards
+    for (;;) {
+        if (down) {
+            const int axis = kd[node].axis;
+            if (axis == 3) {   // leaf: test every triangle, accept iff found && inside(leaf box, ip)
+                const int beg = kd[node].triBegin, cnt = kd[node].triCount;
+                bool found = false;
+                for (int k = 0; k < cnt; k++) {
+                    bump<ST>(c.leafRefs);
+                    int idx = M.refs[beg + k];
+                    if (tri_test<ST>(M.tris + idx, culling, s, d, gamma, l2, l3, c)) { found = true; tri = idx; }
+                }
+                if (found && box_inside(box, s + d * gamma)) return true;
+                down = false;
+                continue;
+            }
+            bump<ST>(c.kdInner);
+            const double split = kd[node].split;
+            const int child0 = kd[node].child0;
+            const int first = comp(s, axis) < split ? 0 : 1;
+            bool went = false;
+            for (int t = 0; t < 2 && !went; t++) {
+                const int ch = t == 0 ? first : 1 - first;
+                Box6 cb = box;                        // BBox::split, bbox.h:205-211
+                if (ch == 0) box_set_hi(cb, axis, split); else box_set_lo(cb, axis, split);
+                if (box_test(cb, s, d, rd)) { box = cb; node = child0 + ch; went = true; }
+            }
+            if (!went) down = false;
+        } else {
+            const int p = kd[node].parent;
+            if (p < 0) return false;      // back above the root: no leaf accepted
+            const int axis = kd[p].axis;
+            const double split = kd[p].split;
+            box_set_lo(box, axis, kd[p].lo);          // parent's box again
+            box_set_hi(box, axis, kd[p].hi);
+            const int which = node - kd[p].child0;
+            const int first = comp(s, axis) < split ? 0 : 1;
+            node = p;
+            if (which == first) {                     // the other child is still to be visited
+                const int ch = 1 - first;
+                Box6 cb = box;
+                if (ch == 0) box_set_hi(cb, axis, split); else box_set_lo(cb, axis, split);
+                if (box_test(cb, s, d, rd)) { box = cb; node = kd[p].child0 + ch; down = true; }
+            }
+        }
+    }
+}
+
+// Geometry part of Node::intersect for node N on the local ray; on a hit returns the local
+// intersection point and fills t / tri / l2 / l3.
+template <bool ST>
+FD bool geom_intersect(const DScene& S, const DNode& N, V3 ls, V3 ld, V3& ipl, double& t, int& tri, double& l2, double& l3, Cnt& c)
+{
+    if (N.geomKind == 0) {   // Plane::intersect, geometry.cpp:30-50
+        bump<ST>(c.prim);
+        const DPlane P = S.planes[N.geomIndex];
+        if (ls.y > P.height && ld.y >= 0) return false;
+        if (ls.y < P.height && ld.y <= 0) return false;
+        double travelByY = fabs(ls.y - P.height);
+        double unitTravel = fabs(ld.y);
+        double scaling = travelByY / unitTravel;
+        V3 ip = ls + ld * scaling;
+        if (fabs(ip.x) > P.limit) return false;
+        if (fabs(ip.z) > P.limit) return false;
+        ipl = ip;
+        t = scaling;
+        return true;
+    }
+    if (N.geomKind == 1) {   // Sphere::intersect, geometry.cpp:52-83
+        bump<ST>(c.prim);
+        const DSphere Sp = S.spheres[N.geomIndex];
+        V3 H = ls - ld3(Sp.O);
+        double A = 1;
+        double B = 2 * dot(ld, H);
+        double C = lengthSqr(H) - Sp.R * Sp.R;
+        double Disc = B * B - 4 * A * C;
+        if (Disc < 0) return false;
+        double sqrtDisc = sqrt(Disc);
+        double p1 = (-B + sqrtDisc) / (2 * A);
+        double p2 = (-B - sqrtDisc) / (2 * A);
+        double smaller = p2 < p1 ? p2 : p1;   // std::min(p1, p2)
+        double larger = p1 < p2 ? p2 : p1;    // std::max(p1, p2)
+        if (larger < 0) return false;
+        double dd = (smaller >= 0) ? smaller : larger;
+        ipl = ls + ld * dd;
+        t = dd;
+        return true;
+    }
+    // mesh
+    const DMesh& M = S.meshes[N.geomIndex];
+    double gamma;
+    if (!mesh_intersect<ST>(M, ls, ld, gamma, tri, l2, l3, c)) return false;
+    ipl = ls + ld * gamma;
+    t = gamma;
+    return true;
+}
+
+// Node::intersect (geometry.cpp:196-208) reduced to what the closest-hit comparison needs.
+template <bool ST>
+FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, double& dist, double& t, int& tri, double& l2, double& l3, Cnt& c)
+{
+    bump<ST>(c.node);
+    const DNode& N = S.nodes[i];
+    V3 ls = mulM(o - ld3(N.T.off), N.T.inv);
+    V3 ldir = normalized(mulM(d, N.T.inv));
+    V3 ipl;
+    if (!geom_intersect<ST>(S, N, ls, ldir, ipl, t, tri, l2, l3, c)) return false;
+    V3 ipw = mulM(ipl, N.T.m) + ld3(N.T.off);
+    dist = length(o - ipw);
+    return true;
+}
+
+// RectLight::intersect (lights.cpp:79-103); point lights are never hit (lights.h:68-71).
+template <bool ST>
+FD bool light_intersect(const DLight& L, V3 o, V3 d, double& dist, Cnt& c)
+{
+    if (L.kind == 0) return false;
+    bump<ST>(c.prim);
+    V3 ls = mulM(o - ld3(L.T.off), L.T.inv);
+    V3 ldir = normalized(mulM(d, L.T.inv));
+    if (ls.y >= 0) return false;
+    if (ldir.y <= 0) return false;
+    double travelByY = fabs(ls.y);
+    double unitTravel = fabs(ldir.y);
+    double scaling = travelByY / unitTravel;
+    V3 ip = ls + ldir * scaling;
+    if (fabs(ip.x) > 0.5 || fabs(ip.z) > 0.5) return false;
+    ip = mulM(ip, L.T.m) + ld3(L.T.off);
+    dist = length(o - ip);
+    return true;
+}
+
+// The two loops of raytrace()/pathtrace(): first node wins ties (strict <), then lights.
+template <bool ST>
+FD void closest_hit(const DScene& S, V3 o, V3 d, HitRec& best, Cnt& c)
+{
+    bump<ST>(c.closest);
+    best.node = -1;
+    best.tri = -1;
+    best.dist = 1e99;
+    best.t = 0; best.l2 = 0; best.l3 = 0;
+    const int nn = S.nNodes;
+    for (int i = 0; i < nn; i++) {
+        double dist, t, l2 = 0, l3 = 0;
+        int tri = -1;
+        if (node_intersect<ST>(S, i, o, d, dist, t, tri, l2, l3, c) && dist < best.dist) {
+            best.node = i; best.tri = tri; best.dist = dist; best.t = t; best.l2 = l2; best.l3 = l3;
+        }
+    }
+    const int nl = S.nLights;
+    for (int i = 0; i < nl; i++) {
+        double dist;
+        if (light_intersect<ST>(S.lights[i], o, d, dist, c) && dist < best.dist) {
+            best.node = -2 - i;
+            best.dist = dist;
+        }
+    }
+}
+
+// visible(a, b), main.cpp:64-80: lights do not occlude; the first node whose (full) intersection
+// lies closer than b ends the loop.
+template <bool ST>
+FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c)
+{
+    bump<ST>(c.shadow);
+    V3 d = b - a;
+    double maxDist = length(a - b);
+    d = normalized(d);
+    const int nn = S.nNodes;
+    for (int i = 0; i < nn; i++) {
+        double dist, t, l2, l3;
+        int tri;
+        if (node_intersect<ST>(S, i, a, d, dist, t, tri, l2, l3, c) && dist < maxDist) return false;
+    }
+    return true;
+}

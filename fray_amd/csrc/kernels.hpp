@@ -1,0 +1,327 @@
+// HIP kernels of the renderer (gfx950, wave64).
+//
+//   k_primary      camera ray through integer (x, y) + closest hit          (MODE_PRIMARY_ID)
+//   k_whitted      raytrace() per pixel, samples looped in order             (MODE_RENDER, gi off)
+//   k_pt_init      path-tracing batch: seeds, pixel jitter, camera rays -> path queue
+//   k_pt_bounce    one pathtrace() iteration for every live path: closest hit, bump, discarded
+//                  spawn, next-event estimation with its shadow ray, real spawn; survivors are
+//                  compacted into the next queue with a wave ballot + one atomic per wave
+//   k_pt_resolve   per pixel, samples summed in sample order (the reference's FP32 order)
+//   k_pack/unpack  bucket-major <-> row-major copies for the multi-GPU gather
+#pragma once
+#include "dev_shade.hpp"
+
+// ---- work item -> pixel ------------------------------------------------------------------------
+FD bool item_pixel(const DFrame& F, int item, int& x, int& y)
+{
+    int k = item / 2304, local = item - k * 2304;
+    int b = F.bucketFirst + k * F.bucketStride;
+    int bx = b % F.BW, by = b / F.BW;
+    x = bx * 48 + local % 48;
+    y = by * 48 + local / 48;
+    return x < F.W && y < F.H;
+}
+
+FD void flush_stats(DStats* st, const Cnt& c)
+{
+    atomicAdd(&st->closest, c.closest); atomicAdd(&st->shadow, c.shadow); atomicAdd(&st->node, c.node);
+    atomicAdd(&st->kdInner, c.kdInner); atomicAdd(&st->leafRefs, c.leafRefs); atomicAdd(&st->tri, c.tri);
+    atomicAdd(&st->prim, c.prim); atomicAdd(&st->smooth, c.smooth); atomicAdd(&st->samples, c.samples);
+    atomicAdd(&st->tex, c.tex);
+}
+FD Cnt zero_cnt() { Cnt c; c.closest = c.shadow = c.node = c.kdInner = c.leafRefs = c.tri = c.prim = c.smooth = c.samples = c.tex = 0; return c; }
+
+// ---- camera (camera.cpp:59-92) ------------------------------------------------------------------
+FD void screen_ray(const DCamera& C, double x, double y, V3& o, V3& d)
+{
+    V3 tl = ld3(C.topLeft);
+    d = tl + (ld3(C.topRight) - tl) * (x / C.w) + (ld3(C.bottomLeft) - tl) * (y / C.h);
+    d = normalized(d);
+    o = ld3(C.pos);
+}
+FD void dof_ray(const DCamera& C, double x, double y, Mt& tab, V3& o, V3& d)
+{
+    screen_ray(C, x, y, o, d);
+    double M = C.focalPlaneDist / dot(ld3(C.frontDir), d);
+    V3 T = ld3(C.pos) + d * M;
+    double u, v;
+    rng_unit_disc(tab, u, v);
+    u *= C.apertureSize;
+    v *= C.apertureSize;
+    o = o + (u * ld3(C.rightDir) + v * ld3(C.upDir));
+    d = normalized(T - o);
+}
+
+// ---- MODE_PRIMARY_ID ------------------------------------------------------------------------------
+template <bool ST>
+__global__ __launch_bounds__(256) void k_primary(DScene S, DCamera C, DFrame F, int nItems, int32_t* __restrict__ hitId,
+                                                 double* __restrict__ hitDist, DStats* st)
+{
+    Cnt c = zero_cnt();
+    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < nItems; item += gridDim.x * blockDim.x) {
+        int x, y;
+        if (!item_pixel(F, item, x, y)) continue;
+        V3 o, d;
+        screen_ray(C, (double)x, (double)y, o, d);
+        HitRec h;
+        closest_hit<ST>(S, o, d, h, c);
+        size_t p = (size_t)y * F.W + x;
+        if (hitId) hitId[p] = h.node;
+        if (hitDist) hitDist[p] = h.dist;
+    }
+    if (ST) flush_stats(st, c);
+}
+
+// ---- Whitted (main.cpp:246-285), shaders without recursion --------------------------------------
+template <bool ST>
+FD C3 raytrace_flat(const DScene& S, V3 o, V3 d, Mt& tab, Cnt& c)
+{
+    HitRec h;
+    closest_hit<ST>(S, o, d, h, c);
+    if (h.node <= -2) return light_color(S.lights[-2 - h.node]);
+    if (h.node < 0) return environment<ST>(S, d, c);
+    const DNode& N = S.nodes[h.node];
+    const DShader& sh = S.shaders[N.shader];
+    HitInfo info;
+    finalize_hit(S, h, o, d, sh.usesUV || N.bumpTex >= 0, info);
+    if (ST && N.geomKind == 3 && S.meshes[N.geomIndex].smooth) c.smooth++;
+    apply_bump<ST>(S, h.node, info, c);
+    if (sh.kind == 0) return ldc(sh.color);                          // ConstantShader::shade
+    return shade_direct<ST>(S, sh, d, info, tab, sh.kind == 2, c);   // Lambert / Phong
+}
+
+__constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0, 0.6}, {0.6, 0.6}};   // main.cpp:55-61
+
+template <bool ST>
+__global__ __launch_bounds__(256) void k_whitted(DScene S, DCamera C, DFrame F, int nItems, float* __restrict__ rgb, DStats* st)
+{
+    Cnt c = zero_cnt();
+    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < nItems; item += gridDim.x * blockDim.x) {
+        int x, y;
+        if (!item_pixel(F, item, x, y)) continue;
+        const uint32_t p = (uint32_t)y * (uint32_t)F.W + (uint32_t)x;
+        C3 avg = c3(0, 0, 0);
+        bool ovf = false;
+        for (int i = 0; i < F.spp; i++) {
+            Mt rnd = mt_seed(sample_seed(F.seed, p, (uint32_t)i));
+            Mt tab = rnd;
+            float ox, oy;
+            if (F.jitter) { ox = rng_float(rnd); oy = rng_float(rnd); }
+            else { ox = (float)kAAOffsets[i][0]; oy = (float)kAAOffsets[i][1]; }
+            double fx = (double)((float)x + ox), fy = (double)((float)y + oy);   // int + float, main.cpp:359
+            V3 o, d;
+            if (C.dof) dof_ray(C, fx, fy, tab, o, d); else screen_ray(C, fx, fy, o, d);
+            bump<ST>(c.samples);
+            avg = avg + raytrace_flat<ST>(S, o, d, tab, c);
+            ovf = ovf || rnd.j > 227 || tab.j > 227;
+        }
+        avg = avg / (float)F.spp;
+        if (ovf) atomicAdd(&st->rngOverflow, 1ull);
+        size_t q = (size_t)p * 3;
+        rgb[q] = avg.r; rgb[q + 1] = avg.g; rgb[q + 2] = avg.b;
+    }
+    if (ST) flush_stats(st, c);
+}
+
+// ---- path tracer (main.cpp:171-244) as a wavefront ---------------------------------------------------
+// Path state, structure of arrays (one lane = one path, consecutive lanes = consecutive entries,
+// so every array is read and written fully coalesced).  92 bytes per path.
+struct PathQueue {
+    double* ox; double* oy; double* oz;
+    double* dx; double* dy; double* dz;
+    float* tr; float* tg; float* tb;      // pathMultiplier
+    float* ar; float* ag; float* ab;      // radiance gathered so far
+    uint32_t* slot;                       // sample-major slot in the batch
+    uint32_t* depthFlags;                 // depth | flags << 16
+    uint32_t* rndJ; uint32_t* rndA; uint32_t* rndB;
+    uint32_t* tabJ; uint32_t* tabA; uint32_t* tabB;
+};
+
+struct PathState {
+    V3 o, d;
+    C3 pm, acc;
+    uint32_t slot;
+    int depth;
+    unsigned flags;
+    Mt rnd, tab;
+};
+
+FD void path_store(const PathQueue& Q, uint32_t i, const PathState& s)
+{
+    Q.ox[i] = s.o.x; Q.oy[i] = s.o.y; Q.oz[i] = s.o.z;
+    Q.dx[i] = s.d.x; Q.dy[i] = s.d.y; Q.dz[i] = s.d.z;
+    Q.tr[i] = s.pm.r; Q.tg[i] = s.pm.g; Q.tb[i] = s.pm.b;
+    Q.ar[i] = s.acc.r; Q.ag[i] = s.acc.g; Q.ab[i] = s.acc.b;
+    Q.slot[i] = s.slot;
+    Q.depthFlags[i] = (uint32_t)s.depth | (s.flags << 16);
+    Q.rndJ[i] = s.rnd.j; Q.rndA[i] = s.rnd.a; Q.rndB[i] = s.rnd.b;
+    Q.tabJ[i] = s.tab.j; Q.tabA[i] = s.tab.a; Q.tabB[i] = s.tab.b;
+}
+FD void path_load(const PathQueue& Q, uint32_t i, PathState& s)
+{
+    s.o = v3(Q.ox[i], Q.oy[i], Q.oz[i]);
+    s.d = v3(Q.dx[i], Q.dy[i], Q.dz[i]);
+    s.pm = c3(Q.tr[i], Q.tg[i], Q.tb[i]);
+    s.acc = c3(Q.ar[i], Q.ag[i], Q.ab[i]);
+    s.slot = Q.slot[i];
+    uint32_t df = Q.depthFlags[i];
+    s.depth = (int)(df & 0xffffu);
+    s.flags = df >> 16;
+    s.rnd.j = Q.rndJ[i]; s.rnd.a = Q.rndA[i]; s.rnd.b = Q.rndB[i];
+    s.tab.j = Q.tabJ[i]; s.tab.a = Q.tabA[i]; s.tab.b = Q.tabB[i];
+}
+
+// Appends the lanes with keep == true to queue Q: one atomicAdd per wave, lanes ranked by a
+// ballot prefix count.
+FD uint32_t wave_append(bool keep, uint32_t* counter)
+{
+    unsigned long long mask = __ballot(keep);
+    uint32_t lane = __lane_id();
+    uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    uint32_t base = 0;
+    if (mask) {
+        int leader = __ffsll((long long)mask) - 1;
+        if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader);
+    }
+    return base + rank;
+}
+
+FD void path_finish(float* __restrict__ sampleRad, DStats* st, const PathState& s, C3 add)
+{
+    C3 r = s.acc + add;
+    size_t q = (size_t)s.slot * 3;
+    sampleRad[q] = r.r; sampleRad[q + 1] = r.g; sampleRad[q + 2] = r.b;
+    if (s.rnd.j > 227 || s.tab.j > 227) atomicAdd(&st->rngOverflow, 1ull);
+}
+
+// Batch = nItems pixels x `chunk` samples starting at sample s0; slot = s * nItems + item.
+template <bool ST>
+__global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFrame F, int nItems, int s0, int chunk, PathQueue Q,
+                                                 uint32_t* qcount, float* __restrict__ sampleRad, DStats* st)
+{
+    Cnt c = zero_cnt();
+    const uint32_t total = (uint32_t)nItems * (uint32_t)chunk;
+    const uint32_t span = (total + 63u) & ~63u;   // whole waves take part in the ballot
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < span; slot += gridDim.x * blockDim.x) {
+        bool live = false;
+        PathState ps;
+        if (slot < total) {
+            int item = (int)(slot % (uint32_t)nItems), s = (int)(slot / (uint32_t)nItems);
+            int x, y;
+            if (item_pixel(F, item, x, y)) {
+                const uint32_t p = (uint32_t)y * (uint32_t)F.W + (uint32_t)x;
+                ps.rnd = mt_seed(sample_seed(F.seed, p, (uint32_t)(s0 + s)));
+                ps.tab = ps.rnd;
+                float ox = rng_float(ps.rnd), oy = rng_float(ps.rnd);           // gi: always jittered (main.cpp:351-353)
+                double fx = (double)((float)x + ox), fy = (double)((float)y + oy);
+                if (C.dof) dof_ray(C, fx, fy, ps.tab, ps.o, ps.d); else screen_ray(C, fx, fy, ps.o, ps.d);
+                ps.pm = c3(1, 1, 1);
+                ps.acc = c3(0, 0, 0);
+                ps.slot = slot;
+                ps.depth = 0;
+                ps.flags = 0;
+                live = true;
+                bump<ST>(c.samples);
+            } else {
+                size_t q = (size_t)slot * 3;
+                sampleRad[q] = 0; sampleRad[q + 1] = 0; sampleRad[q + 2] = 0;
+            }
+        }
+        uint32_t dst = wave_append(live, qcount);
+        if (live) path_store(Q, dst, ps);
+    }
+    if (ST) flush_stats(st, c);
+}
+
+template <bool ST>
+__global__ __launch_bounds__(256) void k_pt_bounce(DScene S, PathQueue Qin, PathQueue Qout, const uint32_t* __restrict__ countIn,
+                                                   uint32_t* countOut, float* __restrict__ sampleRad, DStats* st)
+{
+    Cnt c = zero_cnt();
+    const uint32_t n = *countIn;
+    const uint32_t span = (n + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < span; i += gridDim.x * blockDim.x) {
+        bool cont = false;
+        PathState ps;
+        if (i < n) {
+            path_load(Qin, i, ps);
+            // entry test of pathtrace() (main.cpp:173-176) was applied before this path was queued
+            HitRec h;
+            closest_hit<ST>(S, ps.o, ps.d, h, c);
+            if (h.node <= -2) {                                       // main.cpp:201-208
+                C3 add = (ps.flags & RF_DIFFUSE) ? c3(0, 0, 0) : light_color(S.lights[-2 - h.node]) * ps.pm;
+                path_finish(sampleRad, st, ps, add);
+            } else if (h.node < 0) {                                  // main.cpp:210-215
+                path_finish(sampleRad, st, ps, environment<ST>(S, ps.d, c) * ps.pm);
+            } else {
+                const DNode& N = S.nodes[h.node];
+                const DShader& sh = S.shaders[N.shader];
+                HitInfo info;
+                finalize_hit(S, h, ps.o, ps.d, sh.usesUV || N.bumpTex >= 0, info);
+                if (ST && N.geomKind == 3 && S.meshes[N.geomIndex].smooth) c.smooth++;
+                apply_bump<ST>(S, h.node, info, c);
+                mt_skip(ps.tab, spawn_words(sh));                     // the discarded spawnRay (main.cpp:219-224)
+                C3 contribLight = explicit_light_sample<ST>(S, ps.d, info, ps.pm, sh, ps.rnd, ps.tab, c);
+                PathRay win, wout;
+                win.o = ps.o; win.d = ps.d; win.depth = ps.depth; win.flags = ps.flags;
+                C3 brdf;
+                float pdf;
+                spawn_ray(sh, info, win, ps.tab, wout, brdf, pdf);
+                ps.acc = ps.acc + contribLight;
+                if (pdf == -1.0f) {
+                    path_finish(sampleRad, st, ps, c3(1, 0, 0));
+                } else if (pdf == 0.0f) {
+                    path_finish(sampleRad, st, ps, c3(0, 0, 0));
+                } else {
+                    ps.pm = ps.pm * brdf / pdf;
+                    ps.o = wout.o; ps.d = wout.d; ps.depth = wout.depth; ps.flags = wout.flags;
+                    // entry test of the next pathtrace() call (main.cpp:173-176)
+                    if (ps.depth > S.maxTraceDepth || intensity(ps.pm) < 0.01) path_finish(sampleRad, st, ps, c3(0, 0, 0));
+                    else cont = true;
+                }
+            }
+        }
+        uint32_t dst = wave_append(cont, countOut);
+        if (cont) path_store(Qout, dst, ps);
+    }
+    if (ST) flush_stats(st, c);
+}
+
+// vfb[y][x] = (sum over samples in order) / spp  (main.cpp:348-360).  `sum` carries the running
+// FP32 sum across batches so the addition order is the reference's.
+__global__ __launch_bounds__(256) void k_pt_resolve(DFrame F, int nItems, int s0, int chunk, const float* __restrict__ sampleRad,
+                                                    float* __restrict__ sum, float* __restrict__ rgb)
+{
+    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < nItems; item += gridDim.x * blockDim.x) {
+        int x, y;
+        if (!item_pixel(F, item, x, y)) continue;
+        size_t si = (size_t)item * 3;
+        C3 a = s0 == 0 ? c3(0, 0, 0) : c3(sum[si], sum[si + 1], sum[si + 2]);
+        for (int s = 0; s < chunk; s++) {
+            size_t q = ((size_t)s * nItems + item) * 3;
+            a = a + c3(sampleRad[q], sampleRad[q + 1], sampleRad[q + 2]);
+        }
+        if (s0 + chunk >= F.spp) {
+            a = a / (float)F.spp;
+            size_t p = ((size_t)y * F.W + x) * 3;
+            rgb[p] = a.r; rgb[p + 1] = a.g; rgb[p + 2] = a.b;
+        } else {
+            sum[si] = a.r; sum[si + 1] = a.g; sum[si + 2] = a.b;
+        }
+    }
+}
+
+// ---- multi-GPU bucket exchange ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack(DFrame F, int nItems, int channels, float* __restrict__ frame, float* __restrict__ packed, int unpack)
+{
+    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < nItems; item += gridDim.x * blockDim.x) {
+        int x, y;
+        bool ok = item_pixel(F, item, x, y);
+        for (int ch = 0; ch < channels; ch++) {
+            size_t a = ((size_t)y * F.W + x) * channels + ch, b = (size_t)item * channels + ch;
+            if (unpack) { if (ok) frame[a] = packed[b]; }
+            else packed[b] = ok ? frame[a] : 0.0f;
+        }
+    }
+}

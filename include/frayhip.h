@@ -206,8 +206,13 @@ typedef struct frayhip_frame {
     uint32_t seed;               /* RNG contract seed; the reference uses 42   */
     int32_t  bucket_first, bucket_stride;
     int32_t  spp_chunk;          /* path-tracing samples kept in flight per pixel; 0 = auto */
-    int32_t  _pad;
+    int32_t  flags;              /* FRAYHIP_FRAME_* bits                                   */
 } frayhip_frame;
+
+enum {
+    FRAYHIP_FRAME_STATS = 1,     /* also count rays / node tests / ... into frayhip_stats (uses the
+                                    instrumented kernel variants: slower, same results)     */
+};
 
 typedef struct frayhip_stats {
     uint64_t closest_rays;       /* closest-hit queries (main.cpp:182-199 / 254-271)       */

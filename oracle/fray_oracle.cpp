@@ -456,7 +456,6 @@ struct Tracer {
         local.start = untransformPoint(N.T, ray.start);
         local.dir = untransformDir(N.T, ray.dir);
         if (!geomIntersect(N.geom, local, info)) return false;
-        if (S.geoms[N.geom].kind == FRAYHIP_GEOM_MESH && !(S.meshes[S.geoms[N.geom].index].faceted || S.meshes[S.geoms[N.geom].index].n_normals == 0)) st.smooth++;
         info.ip = transformPoint(N.T, info.ip);
         info.norm = transformDir(N.T, info.norm);
         info.dist = dist(ray.start, info.ip);
@@ -607,6 +606,10 @@ struct Tracer {
                 closest = info;
                 closestNode = i;
             }
+        }
+        if (closestNode >= 0) {   // byte model: the winner's 3 normals + 3 uvs
+            const frayhip_geom_ref& g = S.geoms[S.nodes[closestNode].geom];
+            if (g.kind == FRAYHIP_GEOM_MESH && !(S.meshes[g.index].faceted || S.meshes[g.index].n_normals == 0)) st.smooth++;
         }
         lightIdx = -1;
         for (int i = 0; i < S.n_lights; i++) {

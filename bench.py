@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one step = one frame of cornell_box.fray at 1920x1080, 64 spp, path
+traced (BASELINE.json configs[2], the configuration the metric is quoted on), rendered by the HIP
+library with the scene resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+N > 1 is strong scaling of the same frame: the reference's 48x48 buckets are dealt round-robin to
+the ranks (no data-path collective while rendering), then one RCCL gather of the packed buckets to
+rank 0, inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene, W, H, overrides, description)
+    "cornell_pt64": ("cornell_box.fray", 1920, 1080, dict(gi=1, numPaths=64),
+                     "cornell_box.fray 1920x1080 64spp path trace, maxTraceDepth 6 (BASELINE configs[2])"),
+    "smallpt_pt64": ("smallpt.fray", 1920, 1080, dict(gi=1, numPaths=64), "smallpt.fray 1920x1080 64spp path trace"),
+    "boxed_whitted": ("boxed.fray", 1920, 1080, dict(wantAA=0), "boxed.fray 1920x1080 1spp Whitted (KD meshes, 32 shadow rays/hit)"),
+    "forest_dof16": ("forest.fray", 1920, 1080, dict(wantAA=0, dof=1, numDOFSamples=16, interactive=0), "forest.fray 1920x1080 DOF 16spp Whitted"),
+    "dragon_primary": ("hw9/dragon.fray", 1920, 1080, dict(wantAA=0), "hw9/dragon.fray 1920x1080 primary rays (100k-triangle KD)"),
+}
+
+
+def open_scene(fray_amd, name, W, H, over):
+    s = fray_amd.Scene.parseScene(os.path.join(ROOT, "scenes", name))
+    s.settings.frameWidth, s.settings.frameHeight = W, H
+    for k, v in over.items():
+        if hasattr(s.settings, k):
+            setattr(s.settings, k, v)
+        else:
+            setattr(s.camera, k, v)
+    return s
+
+
+def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0):
+    """The oracle (a scalar C++ port of the reference path) timed on this box's host cores on a
+    bounded sample of the same workload: every `stride`-th 48x48 bucket of the same frame."""
+    from oracle.oracle import Oracle
+    orc = Oracle(abi)
+    name, W, H, over, _ = wl
+    s = open_scene(fray_amd, name, W, H, over)
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    nb = ((W - 1) // 48 + 1) * ((H - 1) // 48 + 1)
+    # calibrate on `threads` buckets spread over the frame, then size the sample for ~target_seconds
+    mode = abi.MODE_RENDER
+    cal_stride = max(1, nb // max(1, min(nb, threads)))
+    t0 = time.time()
+    orc.render(s.desc, mode, seed=seed, bucket_first=0, bucket_stride=cal_stride, threads=threads)
+    dt = max(time.time() - t0, 1e-3)
+    per_bucket = dt / len(range(0, nb, cal_stride))
+    want = int(max(threads, min(nb, target_seconds / per_bucket)))
+    stride = max(1, nb // want)
+    t0 = time.time()
+    _, st = orc.render(s.desc, mode, seed=seed, bucket_first=0, bucket_stride=stride, threads=threads)
+    dt = time.time() - t0
+    rays = st["closest_rays"] + st["shadow_rays"]
+    n_b = len(range(0, nb, stride))
+    s.close()
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "%d of %d buckets (every %d-th 48x48 bucket) of the same frame, all spp, %.1f s, %d threads" % (n_b, nb, stride, dt, threads),
+            "frame_ms_extrapolated": dt * 1e3 * nb / n_b}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell_pt64", choices=sorted(WORKLOADS))
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--spp-chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import fray_amd
+    from fray_amd import abi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    rc = fray_amd.lib.frayhip_init(local_rank)
+    assert rc == 0, fray_amd.lib.frayhip_last_error()
+
+    wl = WORKLOADS[args.workload]
+    name, W, H, over, desc_text = wl
+    scene = open_scene(fray_amd, name, W, H, over)
+    scene.beginRender()
+    mode = abi.MODE_PRIMARY_ID if args.workload.endswith("_primary") else abi.MODE_RENDER
+
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    ids = torch.zeros((H, W), dtype=torch.int32, device=dev) if mode == abi.MODE_PRIMARY_ID else None
+    dists = torch.zeros((H, W), dtype=torch.float64, device=dev) if mode == abi.MODE_PRIMARY_ID else None
+    lib = fray_amd.lib
+    nb_mine = lib.frayhip_bucket_count(W, H, rank, world)
+    nb_max = lib.frayhip_bucket_count(W, H, 0, world)
+    packed = torch.zeros((nb_max * 2304 * 3,), dtype=torch.float32, device=dev) if world > 1 else None
+    gather_list = [torch.zeros_like(packed) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def stream_ptr():
+        return torch.cuda.current_stream().cuda_stream
+
+    def step(stats=False):
+        st = scene.render_device(frame.data_ptr(), seed=args.seed, bucket_first=rank, bucket_stride=world,
+                                 spp_chunk=args.spp_chunk, stats=stats, stream=stream_ptr(), mode=mode,
+                                 d_id_ptr=ids.data_ptr() if ids is not None else None,
+                                 d_dist_ptr=dists.data_ptr() if dists is not None else None)
+        if world > 1 and mode == abi.MODE_RENDER:
+            # the one exchange step: packed buckets -> rank 0 (peer-to-root sends over xGMI), then untile
+            rc = lib.frayhip_pack_buckets_device(frame.data_ptr(), packed.data_ptr(), W, H, 3, rank, world, stream_ptr())
+            assert rc == 0
+            dist.gather(packed, gather_list, dst=0)
+            if rank == 0:
+                for r in range(1, world):
+                    rc = lib.frayhip_unpack_buckets_device(gather_list[r].data_ptr(), frame.data_ptr(), W, H, 3, r, world, stream_ptr())
+                    assert rc == 0
+        return st
+
+    # counters + algorithmic bytes of one frame (instrumented kernels, untimed)
+    st_counts = step(stats=True)
+    counts = torch.tensor([st_counts["closest_rays"], st_counts["shadow_rays"], st_counts["samples"], st_counts["alg_bytes_trace"]],
+                          dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(counts)
+    rays_total = float(counts[0] + counts[1])
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    trace_ms = 0.0
+    trace_launches = 0
+    kernels_ms = 0.0
+    for _ in range(args.steps):
+        st = step()
+        trace_ms += st["ms_trace"]
+        trace_launches += st["trace_launches"]
+        kernels_ms += st["ms_kernels"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0])
+    ms_per_step = elapsed * 1e3 / args.steps
+
+    if rank == 0:
+        # roofline of the dominant kernel on rank 0: algorithmic bytes (SURVEY 8d byte model, from the
+        # counters of this rank's share) / that kernel's launch time measured with HIP events
+        alg_bytes_rank0 = st_counts["alg_bytes_trace"]
+        avg_launch_ms = trace_ms / max(1, trace_launches)
+        bytes_per_launch = alg_bytes_rank0 * args.steps / max(1, trace_launches)
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        kern = {abi.MODE_PRIMARY_ID: "k_primary"}.get(mode, "k_pt_bounce" if scene.settings.gi else "k_whitted")
+        out = {
+            "metric": "Mrays/s (closest-hit + shadow rays) at 1920x1080, 64spp path trace",
+            "value": rays_total / (ms_per_step * 1e-3) / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "reference scene file scenes/%s (unchanged), RNG contract seed %d" % (name, args.seed),
+            "config": {"workload": desc_text, "width": W, "height": H, "spp": scene.samples_per_pixel(),
+                       "rays_per_frame": rays_total, "camera_samples_per_frame": float(counts[2]),
+                       "parallelism": "tiles%d" % world if world > 1 else "single-gpu",
+                       "frame_ms": ms_per_step, "msamples_per_s": float(counts[2]) / (ms_per_step * 1e-3) / 1e6},
+            "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "alg_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms,
+                         "launches_per_step": trace_launches / args.steps,
+                         "note": "algorithmic bytes per SURVEY 8(d); scene tables are L2/LDS resident, so this is not HBM traffic"},
+            "kernel_ms_per_step": kernels_ms / args.steps,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(fray_amd, abi, wl, args.seed) if mode == abi.MODE_RENDER else None
+        print(json.dumps(out), flush=True)
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -450,9 +450,13 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             if (sc->whittedNeedsRecursion) { set_error("frayhip_render: Whitted recursion (Refl / Refr / Layered) is not implemented on the device path yet"); return FRAYHIP_E_UNSUPPORTED; }
             if (!F.jitter && spp > 5) { set_error("frayhip_render: bad sample count"); return FRAYHIP_E_ARG; }
             if (nItems > 0) {
+                // per-thread mt19937 state columns for samples that draw more than 227 words
+                const int grid = grid_for(nItems);
+                int rc = ensure_work(sc, (size_t)grid * 256 * 624 * sizeof(uint32_t));
+                if (rc) return rc;
                 hipEvent_t a = pool_event(sc, 0), b = pool_event(sc, 1);
                 HIP_TRY(hipEventRecord(a, stream));
-                hipLaunchKernelGGL(k_whitted<ST>, dim3(grid_for(nItems)), dim3(256), 0, stream, S, C, F, nItems, d_rgb, sc->d_stats);
+                hipLaunchKernelGGL(k_whitted<ST>, dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, sc->d_stats);
                 HIP_TRY(hipEventRecord(b, stream));
                 nTraceEvents = 2;
             }
@@ -563,6 +567,35 @@ int frayhip_render(frayhip_scene* s, const frayhip_frame* f, float* rgb, int32_t
     }
     cleanup();
     return rc;
+}
+
+__global__ void k_debug_rng(uint32_t seed, int n, float* f, double* d, int32_t* it, int hi, uint32_t* work)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    MtLong g[3];
+    for (int k = 0; k < 3; k++) { g[k].st = work + k; g[k].stride = 3; g[k].reseed(seed); }
+    for (int i = 0; i < n; i++) {
+        f[i] = rng_float(g[0]);
+        d[i] = rng_double(g[1]);
+        it[i] = rng_int0(g[2], hi);
+    }
+}
+
+int frayhip_debug_rng(uint32_t seed, int n, float* floats, double* doubles, int32_t* ints, int int_hi)
+{
+    if (n < 0 || n > 4096 || int_hi < 0) { set_error("frayhip_debug_rng: bad argument"); return FRAYHIP_E_ARG; }
+    float* df = nullptr; double* dd = nullptr; int32_t* di = nullptr; uint32_t* work = nullptr;
+    HIP_TRY(hipMalloc((void**)&df, 4096 * 4));
+    HIP_TRY(hipMalloc((void**)&dd, 4096 * 8));
+    HIP_TRY(hipMalloc((void**)&di, 4096 * 4));
+    HIP_TRY(hipMalloc((void**)&work, 3 * 624 * 4));
+    hipLaunchKernelGGL(k_debug_rng, dim3(1), dim3(64), 0, nullptr, seed, n, df, dd, di, int_hi, work);
+    HIP_TRY(hipDeviceSynchronize());
+    if (floats) HIP_TRY(hipMemcpy(floats, df, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (doubles) HIP_TRY(hipMemcpy(doubles, dd, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (ints) HIP_TRY(hipMemcpy(ints, di, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(df); (void)hipFree(dd); (void)hipFree(di); (void)hipFree(work);
+    return FRAYHIP_OK;
 }
 
 static int pack_impl(const float* d_frame, float* d_packed, int width, int height, int channels, int first, int stride, void* hip_stream, int unpack)

@@ -13,7 +13,7 @@
 #pragma once
 #include "dev_math.hpp"
 
-struct Mt { uint32_t j, a, b; };
+struct Mt { uint32_t j, a, b; FD uint32_t next(); };
 
 FD uint32_t mt_lcg(uint32_t x, uint32_t i) { return 1812433253u * (x ^ (x >> 30)) + i; }
 
@@ -43,6 +43,8 @@ FD uint32_t mt_next(Mt& r)
     return v;
 }
 
+FD uint32_t Mt::next() { return mt_next(*this); }
+
 FD void mt_skip(Mt& r, int n)   // draws whose values the reference discards
 {
     for (int i = 0; i < n; i++) {
@@ -53,19 +55,21 @@ FD void mt_skip(Mt& r, int n)   // draws whose values the reference discards
 }
 
 // Random::randfloat: generate_canonical<float, 24> -- one word, float(u) / 2^32, clamped below 1.
-FD float rng_float(Mt& r)
+template <class G>
+FD float rng_float(G& r)
 {
-    float f = (float)mt_next(r);
+    float f = (float)r.next();
     f = f / 4294967296.0f;
     if (f >= 1.0f) f = 0x1.fffffep-1f;   // nextafter(1.0f, 0.0f)
     return f;
 }
 
 // Random::randdouble: generate_canonical<double, 53> -- two words, (u0 + u1 * 2^32) / 2^64.
-FD double rng_double(Mt& r)
+template <class G>
+FD double rng_double(G& r)
 {
-    double sum = (double)mt_next(r);
-    sum = sum + (double)mt_next(r) * 4294967296.0;
+    double sum = (double)r.next();
+    sum = sum + (double)r.next() * 4294967296.0;
     double v = sum / 18446744073709551616.0;
     if (v >= 1.0) v = 0x1.fffffffffffffp-1;   // nextafter(1.0, 0.0)
     return v;
@@ -73,15 +77,16 @@ FD double rng_double(Mt& r)
 
 // Random::randint(0, hi): Lemire's nearly divisionless method on a 32-bit generator
 // (uniform_int_distribution::_S_nd<uint64_t>).
-FD int rng_int0(Mt& r, int hi)
+template <class G>
+FD int rng_int0(G& r, int hi)
 {
     uint32_t range = (uint32_t)hi + 1u;
-    uint64_t product = (uint64_t)mt_next(r) * (uint64_t)range;
+    uint64_t product = (uint64_t)r.next() * (uint64_t)range;
     uint32_t low = (uint32_t)product;
     if (low < range) {
         uint32_t threshold = (0u - range) % range;
         while (low < threshold) {
-            product = (uint64_t)mt_next(r) * (uint64_t)range;
+            product = (uint64_t)r.next() * (uint64_t)range;
             low = (uint32_t)product;
         }
     }
@@ -89,13 +94,60 @@ FD int rng_int0(Mt& r, int hi)
 }
 
 // Random::unitDiscSample, random_generator.cpp:71-80
-FD void rng_unit_disc(Mt& r, double& x, double& y)
+template <class G>
+FD void rng_unit_disc(G& r, double& x, double& y)
 {
     double angle = rng_double(r) * 2 * FRAY_PI;
     double rad = sqrt(rng_double(r));
     x = sin(angle) * rad;
     y = cos(angle) * rad;
 }
+
+// Generator without the 227-word limit, for the Whitted kernel (a Lambert hit under a 15x15
+// RectLight alone draws 450 words; glossy reflections draw an unbounded number).  The first 227
+// outputs come from the register recurrence above; past that the full 624-word state is
+// materialised in a per-thread slice of a global workspace (word k of thread t at
+// st[k * stride + t], so lanes in step touch consecutive addresses) and advanced with the
+// standard in-place twist.
+struct MtLong {
+    Mt r;
+    uint32_t seed;
+    uint32_t* st;       // this thread's column of the workspace
+    uint32_t stride;
+    int idx;            // next output position in the materialised state, -1 = not materialised
+
+    FD void reseed(uint32_t s) { r = mt_seed(s); seed = s; idx = -1; }
+    FD uint32_t& w(int k) { return st[(size_t)k * stride]; }
+    FD static uint32_t tw(uint32_t u, uint32_t v)
+    {
+        uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+        return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    FD void twist()
+    {
+        for (int k = 0; k < 227; k++) w(k) = w(k + 397) ^ tw(w(k), w(k + 1));
+        for (int k = 227; k < 623; k++) w(k) = w(k - 227) ^ tw(w(k), w(k + 1));
+        w(623) = w(396) ^ tw(w(623), w(0));
+    }
+    FD uint32_t next()
+    {
+        if (r.j < 227) return mt_next(r);
+        if (idx < 0) {                       // materialise: seeding recurrence, then the first twist
+            uint32_t x = seed;
+            w(0) = x;
+            for (uint32_t i = 1; i < 624; i++) { x = mt_lcg(x, i); w((int)i) = x; }
+            twist();
+            idx = 227;
+        }
+        if (idx >= 624) { twist(); idx = 0; }
+        uint32_t v = w(idx++);
+        v ^= v >> 11;
+        v ^= (v << 7) & 0x9d2c5680u;
+        v ^= (v << 15) & 0xefc60000u;
+        v ^= v >> 18;
+        return v;
+    }
+};
 
 // Per-(pixel, sample) seed of the RNG contract; the oracle applies the same function
 // (oracle/fray_oracle.cpp sample_seed).

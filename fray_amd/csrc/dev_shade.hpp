@@ -156,7 +156,8 @@ FD C3 environment(const DScene& S, V3 dir, Cnt& c)
 // ---- lights (lights.h:41-47, lights.cpp:31-77,105-108) ---------------------------------------------
 FD int light_num_samples(const DLight& L) { return L.kind == 0 ? 1 : L.xSubd * L.ySubd; }
 FD C3 light_color(const DLight& L) { return ldc(L.color) * L.power; }
-FD void light_nth_sample(const DLight& L, int idx, V3 shadePos, Mt& tab, V3& samplePos, C3& color)
+template <class G>
+FD void light_nth_sample(const DLight& L, int idx, V3 shadePos, G& tab, V3& samplePos, C3& color)
 {
     if (L.kind == 0) {
         samplePos = ld3(L.pos);
@@ -189,8 +190,8 @@ FD double light_solid_angle(const DLight& L, V3 ip)
 }
 
 // ---- Whitted: Lambert::shade / Phong::shade (shading.cpp:48-80, 101-144) ---------------------------
-template <bool ST>
-FD C3 shade_direct(const DScene& S, const DShader& sh, V3 rayDir, const HitInfo& info, Mt& tab, bool phong, Cnt& c)
+template <bool ST, class G>
+FD C3 shade_direct(const DScene& S, const DShader& sh, V3 rayDir, const HitInfo& info, G& tab, bool phong, Cnt& c)
 {
     C3 diffuse = ldc(sh.color);
     if (sh.texture >= 0) diffuse = diffuse * texture_sample<ST>(S, sh.texture, rayDir, info, c);

@@ -278,6 +278,10 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitRec& best, Cnt& c)
             best.node = i; best.tri = tri; best.dist = dist; best.t = t; best.l2 = l2; best.l3 = l3;
         }
     }
+    if (ST && best.node >= 0) {   // byte model: the winner's corner normals / uvs
+        const DNode& W = S.nodes[best.node];
+        if (W.geomKind == 3 && S.meshes[W.geomIndex].smooth) c.smooth++;
+    }
     const int nl = S.nLights;
     for (int i = 0; i < nl; i++) {
         double dist;

@@ -39,7 +39,8 @@ FD void screen_ray(const DCamera& C, double x, double y, V3& o, V3& d)
     d = normalized(d);
     o = ld3(C.pos);
 }
-FD void dof_ray(const DCamera& C, double x, double y, Mt& tab, V3& o, V3& d)
+template <class G>
+FD void dof_ray(const DCamera& C, double x, double y, G& tab, V3& o, V3& d)
 {
     screen_ray(C, x, y, o, d);
     double M = C.focalPlaneDist / dot(ld3(C.frontDir), d);
@@ -73,8 +74,8 @@ __global__ __launch_bounds__(256) void k_primary(DScene S, DCamera C, DFrame F, 
 }
 
 // ---- Whitted (main.cpp:246-285), shaders without recursion --------------------------------------
-template <bool ST>
-FD C3 raytrace_flat(const DScene& S, V3 o, V3 d, Mt& tab, Cnt& c)
+template <bool ST, class G>
+FD C3 raytrace_flat(const DScene& S, V3 o, V3 d, G& tab, Cnt& c)
 {
     HitRec h;
     closest_hit<ST>(S, o, d, h, c);
@@ -84,18 +85,20 @@ FD C3 raytrace_flat(const DScene& S, V3 o, V3 d, Mt& tab, Cnt& c)
     const DShader& sh = S.shaders[N.shader];
     HitInfo info;
     finalize_hit(S, h, o, d, sh.usesUV || N.bumpTex >= 0, info);
-    if (ST && N.geomKind == 3 && S.meshes[N.geomIndex].smooth) c.smooth++;
     apply_bump<ST>(S, h.node, info, c);
     if (sh.kind == 0) return ldc(sh.color);                          // ConstantShader::shade
-    return shade_direct<ST>(S, sh, d, info, tab, sh.kind == 2, c);   // Lambert / Phong
+    return shade_direct<ST, G>(S, sh, d, info, tab, sh.kind == 2, c);   // Lambert / Phong
 }
 
 __constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0, 0.6}, {0.6, 0.6}};   // main.cpp:55-61
 
 template <bool ST>
-__global__ __launch_bounds__(256) void k_whitted(DScene S, DCamera C, DFrame F, int nItems, float* __restrict__ rgb, DStats* st)
+__global__ __launch_bounds__(256) void k_whitted(DScene S, DCamera C, DFrame F, int nItems, float* __restrict__ rgb, uint32_t* mtWork, DStats* st)
 {
     Cnt c = zero_cnt();
+    MtLong tab;
+    tab.stride = gridDim.x * blockDim.x;
+    tab.st = mtWork + (blockIdx.x * blockDim.x + threadIdx.x);
     for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < nItems; item += gridDim.x * blockDim.x) {
         int x, y;
         if (!item_pixel(F, item, x, y)) continue;
@@ -103,8 +106,9 @@ __global__ __launch_bounds__(256) void k_whitted(DScene S, DCamera C, DFrame F, 
         C3 avg = c3(0, 0, 0);
         bool ovf = false;
         for (int i = 0; i < F.spp; i++) {
-            Mt rnd = mt_seed(sample_seed(F.seed, p, (uint32_t)i));
-            Mt tab = rnd;
+            const uint32_t sd = sample_seed(F.seed, p, (uint32_t)i);
+            tab.reseed(sd);
+            Mt rnd = tab.r;
             float ox, oy;
             if (F.jitter) { ox = rng_float(rnd); oy = rng_float(rnd); }
             else { ox = (float)kAAOffsets[i][0]; oy = (float)kAAOffsets[i][1]; }
@@ -112,8 +116,8 @@ __global__ __launch_bounds__(256) void k_whitted(DScene S, DCamera C, DFrame F, 
             V3 o, d;
             if (C.dof) dof_ray(C, fx, fy, tab, o, d); else screen_ray(C, fx, fy, o, d);
             bump<ST>(c.samples);
-            avg = avg + raytrace_flat<ST>(S, o, d, tab, c);
-            ovf = ovf || rnd.j > 227 || tab.j > 227;
+            avg = avg + raytrace_flat<ST, MtLong>(S, o, d, tab, c);
+            ovf = ovf || rnd.j > 227;
         }
         avg = avg / (float)F.spp;
         if (ovf) atomicAdd(&st->rngOverflow, 1ull);
@@ -259,8 +263,7 @@ __global__ __launch_bounds__(256) void k_pt_bounce(DScene S, PathQueue Qin, Path
                 const DShader& sh = S.shaders[N.shader];
                 HitInfo info;
                 finalize_hit(S, h, ps.o, ps.d, sh.usesUV || N.bumpTex >= 0, info);
-                if (ST && N.geomKind == 3 && S.meshes[N.geomIndex].smooth) c.smooth++;
-                apply_bump<ST>(S, h.node, info, c);
+                            apply_bump<ST>(S, h.node, info, c);
                 mt_skip(ps.tab, spawn_words(sh));                     // the discarded spawnRay (main.cpp:219-224)
                 C3 contribLight = explicit_light_sample<ST>(S, ps.d, info, ps.pm, sh, ps.rnd, ps.tab, c);
                 PathRay win, wout;

@@ -1,6 +1,7 @@
 """Host-side mirror of the reference's Scene / render() interface over the C ABI."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -17,6 +18,16 @@ class FrayError(RuntimeError):
 
 
 def _load():
+    # PyTorch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, no versioned SONAME).
+    # A process must not end up with two HIP runtimes: whichever is loaded second finds no GPU and
+    # stream handles do not carry over.  Loading torch first puts its runtime in the global symbol
+    # scope, and libfrayhip.so then binds to that same runtime.  (Hosts that never use torch --
+    # e.g. the reference's C++ main() -- just get /opt/rocm's runtime.)
+    if "torch" not in sys.modules and not os.environ.get("FRAYHIP_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(_LIB_PATH):
         raise ImportError(
             "fray_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -279,6 +279,13 @@ int  frayhip_unpack_buckets_device(const float* d_packed, float* d_frame, int wi
 /* vfb -> RGB32 with clamp, no gamma (displayVFB, sdl.cpp:63-74; Color::toRGB32, color.h:59-65). */
 int  frayhip_to_rgb32(const float* rgb, uint32_t* out, int n_pixels);
 
+/* Test hook: runs the device restatement of the reference's random numbers (std::mt19937 +
+ * libstdc++ distributions, random_generator.cpp:41-80) for one seed and returns, for i < n,
+ * the i-th randfloat() of a fresh generator, the i-th randdouble() of a second and the i-th
+ * randint(0, int_hi) of a third (host buffers, any may be NULL; n <= 4096, which crosses the
+ * generator's 227-word register window and two full state twists). */
+int  frayhip_debug_rng(uint32_t seed, int n, float* floats, double* doubles, int32_t* ints, int int_hi);
+
 const char* frayhip_last_error(void);
 int  frayhip_abi_version(void);
 /* sizeof() of a struct of this header by name ("frayhip_mesh", ...), -1 if unknown: lets a

@@ -1,0 +1,67 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/frayhip.h declares."""
+import ctypes as C
+import os
+import re
+
+from conftest import ROOT
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "frayhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(frayhip_\w+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(fray, abi):
+    names = header_functions()
+    assert names, "no declarations found"
+    assert sorted(abi.SYMBOLS) == names, "fray_amd/abi.py and include/frayhip.h disagree on the entry points"
+    for n in names:
+        assert hasattr(fray.lib, n), n
+
+
+def test_struct_layouts_match(fray, abi):
+    for name, t in abi.STRUCTS.items():
+        assert fray.lib.frayhip_sizeof(name.encode()) == C.sizeof(t), name
+    assert fray.lib.frayhip_sizeof(b"nope") == -1
+    assert fray.lib.frayhip_abi_version() == abi.ABI_VERSION
+
+
+def test_every_header_struct_is_mirrored(abi):
+    src = open(os.path.join(ROOT, "include", "frayhip.h")).read()
+    structs = set(re.findall(r"typedef struct (frayhip_\w+)\s*\{", src))
+    assert structs == set(abi.STRUCTS), structs ^ set(abi.STRUCTS)
+
+
+def test_bucket_count(fray):
+    f = fray.lib.frayhip_bucket_count
+    assert f(1920, 1080, 0, 1) == 40 * 23
+    assert f(48, 48, 0, 1) == 1 and f(49, 48, 0, 1) == 2
+    assert sum(f(1920, 1080, r, 8) for r in range(8)) == 920
+    assert f(100, 100, 3, 2) < 0 and f(0, 10, 0, 1) < 0
+
+
+def test_to_rgb32(fray):
+    import numpy as np
+    rgb = np.array([[0, 0.5, 1.0], [-1, 2, 0.25], [1 / 255.0, 0.4999 / 255, 0.5001 / 255]], np.float32)
+    out = np.zeros(3, np.uint32)
+    assert fray.lib.frayhip_to_rgb32(rgb.ctypes.data, out.ctypes.data, 3) == 0
+    assert out[0] == (0 << 16) | (128 << 8) | 255      # floor(0.5*255 + 0.5) = 128
+    assert out[1] == (0 << 16) | (255 << 8) | 64
+    assert out[2] == (1 << 16) | (0 << 8) | 1
+
+
+def test_errors_do_not_raise_across_the_abi(fray, abi):
+    hs = C.c_void_p()
+    rc = fray.lib.frayhip_scene_parse(b"/nonexistent/scene.fray", C.byref(hs))
+    assert rc == abi.E_PARSE and b"Cannot open" in fray.lib.frayhip_last_error()
+    assert fray.lib.frayhip_scene_parse(None, C.byref(hs)) == abi.E_ARG
+
+
+def test_product_does_not_reach_into_the_oracle():
+    """Nothing under fray_amd/ (nor bench.py outside its cpu_baseline leg) may import the oracle."""
+    for dp, _, files in os.walk(os.path.join(ROOT, "fray_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                text = open(os.path.join(dp, fn), errors="replace").read()
+                assert "oracle" not in text.lower() or fn in ("dev_rng.hpp",), (fn, "mentions the oracle")

@@ -1,0 +1,230 @@
+"""The .fray parser / OBJ / BMP loaders behave like the reference's (scene.cpp:403-570, mesh.cpp:203-258,
+bitmap.cpp:117-195) on the edge cases its grammar has."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import open_scene
+
+
+def parse(fray, tmp_path, text, files=None):
+    for name, data in (files or {}).items():
+        p = tmp_path / name
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(data if isinstance(data, bytes) else data.encode())
+    f = tmp_path / "scene.fray"
+    f.write_text(text)
+    return fray.Scene.parseScene(str(f))
+
+
+BASE = """
+Camera camera {
+	position (1, 2, 3)
+}
+"""
+
+
+def test_defaults_follow_the_reference(fray, tmp_path):
+    s = parse(fray, tmp_path, BASE)
+    st, cam = s.settings, s.camera
+    assert (st.frameWidth, st.frameHeight, st.wantAA, st.maxTraceDepth, st.gi, st.numPaths, st.wantPrepass) == (800, 600, 1, 4, 0, 10, 1)
+    assert (cam.fov, cam.aspectRatio, cam.fNumber, cam.focalPlaneDist, cam.numDOFSamples, cam.dof) == (90.0, 1.3333, 2.0, 5.0, 32, 0)
+    assert list(cam.pos) == [1, 2, 3]
+    assert s.samples_per_pixel() == 5
+
+
+def test_comments_singletons_and_quotes(fray, tmp_path):
+    text = """
+// a comment
+# another
+GlobalSettings {
+	frameWidth 123   // trailing comment
+	frameHeight 77   # trailing hash comment
+	wantAA off
+	gi on
+	pathsPerPixel 7
+}
+/* block comment opens at line start
+Camera nope { position (9,9,9) }
+*/
+Camera camera {
+	position (1, 2, 3)
+	dof false
+}
+Plane p {
+	y 2
+	limit "64"
+}
+Lambert l { }
+Lambert l2 {
+	color (0.5, 0.25, 0.125)
+}
+Node n {
+	geometry p
+	shader l2
+	weirdProperty 3
+}
+Node supernode {
+	geometry p
+}
+"""
+    # `Lambert l { }` on one line is NOT valid in the reference grammar (4 tokens): it must fail
+    with pytest.raises(fray.FrayError):
+        parse(fray, tmp_path, text)
+    s = parse(fray, tmp_path, text.replace("Lambert l { }\n", ""))
+    assert (s.settings.frameWidth, s.settings.frameHeight, s.settings.wantAA, s.settings.gi, s.settings.numPaths) == (123, 77, 0, 1, 7)
+    assert list(s.camera.pos) == [1, 2, 3]
+    assert s.desc.n_planes == 1 and s.desc.planes[0].height == 2 and s.desc.planes[0].limit == 64
+    assert s.desc.n_nodes == 1            # the shader-less node is dropped from the render list (scene.cpp:563-568)
+    assert list(s.desc.shaders[s.desc.nodes[0].shader].color) == [0.5, 0.25, 0.125]
+    assert s.samples_per_pixel() == 7
+
+
+def test_transform_lines_apply_in_file_order(fray, tmp_path):
+    text = BASE + """
+Plane p {
+}
+Lambert l {
+}
+Node a {
+	geometry p
+	shader l
+	scale (2, 2, 2)
+	rotate (90, 0, 0)
+	translate (1, 0, 0)
+}
+Node b {
+	geometry p
+	shader l
+	translate (1, 0, 0)
+	rotate (90, 0, 0)
+	scale (2, 2, 2)
+}
+"""
+    s = parse(fray, tmp_path, text)
+    a, b = s.desc.nodes[0].T, s.desc.nodes[1].T
+    ma, mb = np.array(a.m).reshape(3, 3), np.array(b.m).reshape(3, 3)
+    c, sn = np.cos(np.pi / 2), np.sin(np.pi / 2)
+    ry = np.array([[c, 0, sn], [0, 1, 0], [-sn, 0, c]])         # rotationAroundY, matrix.cpp:41-50
+    assert np.allclose(ma, 2 * np.eye(3) @ ry) and np.allclose(mb, ry @ (2 * np.eye(3)))
+    assert list(a.offset) == [1, 0, 0] and list(b.offset) == [1, 0, 0]
+    for T in (a, b):
+        assert np.allclose(np.array(T.m).reshape(3, 3) @ np.array(T.invM).reshape(3, 3), np.eye(3))
+
+
+def test_layered_lines_and_forward_references(fray, tmp_path):
+    text = BASE + """
+Layered glass {
+	layer refr (1, 1, 1)
+	layer refl (0.25, 0.5, 0.75) fresnel
+}
+Refr refr {
+	ior 1.5
+	multiplier 0.96
+}
+Refl refl {
+	glossiness 0.5
+	numSamples 7
+}
+Fresnel fresnel {
+	ior 1.5
+}
+Sphere s {
+	R 2
+}
+Node n {
+	geometry s
+	shader glass
+}
+"""
+    s = parse(fray, tmp_path, text)
+    sh = s.desc.shaders[0]
+    assert sh.kind == 5 and sh.layer_count == 2
+    l0, l1 = s.desc.layers[sh.layer_begin], s.desc.layers[sh.layer_begin + 1]
+    assert (l0.shader, l0.texture, list(l0.opacity)) == (1, -1, [1, 1, 1])
+    assert (l1.shader, l1.texture, list(l1.opacity)) == (2, 0, [0.25, 0.5, 0.75])
+    refl = s.desc.shaders[2]
+    assert refl.numSamples == 7 and refl.deflectionScaling == 10.0 ** (2 - 4 * 0.5)
+    assert abs(s.desc.shaders[1].mult[0] - np.float32(0.96)) == 0
+
+
+@pytest.mark.parametrize("bad", [
+    "Wibble x {\n}\n",                                   # unknown class
+    "Camera camera {\n",                                 # unfinished block
+    "Camera camera {\n\tposition (1, 2)\n}\n",           # bad vector
+    "Camera camera {\n\tposition (1,2,3)\n\tfov 500\n}\n",   # range check (camera.h:61)
+    BASE + "Mesh m {\n\tfile \"missing.obj\"\n}\n",      # missing file
+    BASE + "Node n {\n\tgeometry nope\n}\n",             # unresolved name
+    "Plane p {\n}\n",                                     # no camera
+])
+def test_malformed_scenes_are_rejected_with_a_message(fray, tmp_path, bad):
+    with pytest.raises(fray.FrayError) as e:
+        parse(fray, tmp_path, bad)
+    assert e.value.code == -2 and len(str(e.value)) > 20
+
+
+def test_obj_fan_triangulation_and_dummy_indices(fray, tmp_path):
+    obj = """# quad + triangle, one face with missing indices
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+vt 0 0
+vt 1 0
+vt 1 1
+f 1/1 2/2 3/3 4
+f 1 2 3
+"""
+    s = parse(fray, tmp_path, BASE + 'Mesh m {\n\tfile "m.obj"\n}\nLambert l {\n}\nNode n {\n\tgeometry m\n\tshader l\n}\n', {"m.obj": obj})
+    m = s.desc.meshes[0]
+    assert m.n_triangles == 3 and m.n_vertices == 5 and m.n_uvs == 4 and m.n_normals == 0
+    assert m.faceted == 1 and m.has_kd == 0          # no normals -> faceted (mesh.cpp:70); <= 20 tris -> no tree
+    t = [m.triangles[i] for i in range(3)]
+    assert [list(x.v) for x in t] == [[1, 2, 3], [1, 3, 4], [1, 2, 3]]      # fan around the first corner
+    assert list(t[1].t) == [1, 3, 0]                                        # missing uv index -> dummy 0
+    assert list(m.bbox_min) == [0, 0, 0] and list(m.bbox_max) == [1, 1, 0]
+    assert list(t[0].gnormal) == [0, 0, 1] and list(t[0].ABcrossAC) == [0, 0, 1]
+    assert list(t[0].dNdx) == [0, 0, 0]              # no normals -> no tangent frame (mesh.cpp:306-309)
+
+
+def bmp24(w, h, px):
+    row = (w * 3 + 3) // 4 * 4
+    data = b""
+    for y in reversed(range(h)):
+        r = b"".join(struct.pack("BBB", *px(x, y)[::-1]) for x in range(w))
+        data += r + b"\0" * (row - len(r))
+    hdr = b"BM" + struct.pack("<iii", 54 + len(data), 0, 54) + struct.pack("<iiiHHiiiiii", 40, w, h, 1, 24, 0, 0, 0, 0, 0, 0)
+    return hdr + data
+
+
+def test_bmp_loader_and_bump_differentiation(fray, tmp_path):
+    px = lambda x, y: (x * 40, y * 60, 255 if (x + y) % 2 else 0)
+    files = {"t.bmp": bmp24(5, 3, px)}
+    text = BASE + 'BitmapTexture t {\n\tfile "t.bmp"\n\tscaling 4\n}\nBumpTexture b {\n\tfile "t.bmp"\n\tstrength 3\n}\n'
+    s = parse(fray, tmp_path, text, files)
+    t, b = s.desc.textures[0], s.desc.textures[1]
+    assert (t.width, t.height, t.scaling) == (5, 3, 0.25) and (b.bumpIntensity, b.scaling) == (3.0, 1.0)
+    tex = np.ctypeslib.as_array(s.desc.texels, shape=(s.desc.n_texels,))
+    img = tex[t.texel_offset:t.texel_offset + 45].reshape(3, 5, 3)
+    want = np.array([[[c / 255.0 for c in px(x, y)] for x in range(5)] for y in range(3)], np.float32)
+    assert np.array_equal(img, want)
+    d = tex[b.texel_offset:b.texel_offset + 45].reshape(3, 5, 3)
+    inten = (want[..., 0] + want[..., 1] + want[..., 2]) / np.float32(3)
+    assert np.array_equal(d[..., 0], inten - np.roll(inten, -1, axis=1))      # bitmap.cpp:300-315
+    assert np.array_equal(d[..., 1], inten - np.roll(inten, -1, axis=0))
+    assert np.all(d[..., 2] == 0)
+
+
+def test_shipped_scenes_parse(fray):
+    for name, nodes, lights in [("boxed.fray", 9, 2), ("zaphod.fray", 1, 1), ("cornell_box.fray", 7, 1), ("forest.fray", 4, 1),
+                                ("smallpt.fray", 7, 1), ("hw9/dragon.fray", 2, 1), ("hw12/sphtri.fray", 1, 3)]:
+        s = open_scene(fray, name)
+        assert (s.desc.n_nodes, s.desc.n_lights) == (nodes, lights), name
+        s.close()
+    s = open_scene(fray, "cornell_box.fray")
+    L = s.desc.lights[0]
+    assert L.kind == 1 and (L.xSubd, L.ySubd) == (4, 4) and L.area == float(np.float32(130) * np.float32(105))
+    assert list(L.center) == [278, 547.7, 279.5]

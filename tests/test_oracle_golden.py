@@ -1,0 +1,69 @@
+"""Pins the CPU oracle (and the host scene layer it is fed by) to outputs of the unmodified
+reference: the known-answer hashes and KD statistics the survey measured (tests/golden)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, open_scene
+
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "primary_hashes.json")))
+
+
+@pytest.mark.parametrize("case", GOLD["cases"], ids=lambda c: "%s-%dx%d" % (c["scene"], c["w"], c["h"]))
+def test_oracle_primary_hits_match_reference_hashes(fray, abi, oracle, case):
+    s = open_scene(fray, case["scene"], case["w"], case["h"], wantAA=0)
+    ids, dist, st = oracle.render(s.desc, abi.MODE_PRIMARY_ID)
+    assert int((ids != -1).sum()) == case["hits"]
+    assert oracle.fnv(ids) == case["id"]
+    assert oracle.fnv(dist) == case["dist"]
+    assert st["closest_rays"] == case["w"] * case["h"]
+    assert np.all(dist[ids == -1] == 1e99)
+    s.close()
+
+
+def mesh_stats(desc, i):
+    m = desc.meshes[i]
+    kd = [m.kdnodes[k] for k in range(m.n_kdnodes)]
+    leaves = [k for k in kd if k.axis == 3]
+    return {"tris": m.n_triangles, "nodes": m.n_kdnodes, "inner": len(kd) - len(leaves), "leaves": len(leaves),
+            "refs": m.n_trirefs, "max_depth": m.kd_max_depth,
+            "empty_leaves": sum(1 for k in leaves if k.tri_count == 0),
+            "leaves_over_20": sum(1 for k in leaves if k.tri_count > 20),
+            "max_leaf": max([k.tri_count for k in leaves] or [0])}
+
+
+@pytest.mark.parametrize("scene,mesh_index,obj", [("boxed.fray", 0, "geom/teapot_hires.obj"), ("boxed.fray", 1, "geom/heart.obj"),
+                                                  ("boxed.fray", 2, "geom/truncated_cube.obj"), ("forest.fray", 2, "geom/newwine.obj"),
+                                                  ("hw9/dragon.fray", 0, "hw9/dragon.obj")])
+def test_kd_builder_reproduces_reference_tree_statistics(fray, scene, mesh_index, obj):
+    s = open_scene(fray, scene)
+    got = mesh_stats(s.desc, mesh_index)
+    want = GOLD["kd_stats"][obj]
+    for k, v in want.items():
+        assert got[k] == v, (obj, k, got[k], v)
+    s.close()
+
+
+def test_kd_tree_structure_invariants(fray):
+    s = open_scene(fray, "boxed.fray")
+    m = s.desc.meshes[0]
+    seen_children = set()
+    refs = 0
+    for i in range(m.n_kdnodes):
+        k = m.kdnodes[i]
+        if k.axis == 3:
+            assert k.child0 == -1
+            assert 0 <= k.tri_begin and k.tri_begin + k.tri_count <= m.n_trirefs
+            refs += k.tri_count
+        else:
+            assert 0 <= k.axis <= 2 and k.child0 > i and k.child0 + 1 < m.n_kdnodes
+            assert m.kdnodes[k.child0].parent == i and m.kdnodes[k.child0 + 1].parent == i
+            assert k.child0 not in seen_children
+            seen_children.add(k.child0)
+    assert refs == m.n_trirefs and m.kdnodes[0].parent == -1
+    # meshes of <= 20 triangles get no tree (mesh.cpp:85)
+    c = open_scene(fray, "cornell_box.fray")
+    assert all(c.desc.meshes[i].has_kd == 0 and c.desc.meshes[i].n_kdnodes == 0 for i in range(c.desc.n_meshes))
+    s.close(); c.close()

@@ -111,10 +111,8 @@ def main():
     ids = torch.zeros((H, W), dtype=torch.int32, device=dev) if mode == abi.MODE_PRIMARY_ID else None
     dists = torch.zeros((H, W), dtype=torch.float64, device=dev) if mode == abi.MODE_PRIMARY_ID else None
     lib = fray_amd.lib
-    nb_mine = lib.frayhip_bucket_count(W, H, rank, world)
-    nb_max = lib.frayhip_bucket_count(W, H, 0, world)
-    packed = torch.zeros((nb_max * 2304 * 3,), dtype=torch.float32, device=dev) if world > 1 else None
-    gather_list = [torch.zeros_like(packed) for _ in range(world)] if (world > 1 and rank == 0) else None
+    from fray_amd import tiles
+    gatherer = tiles.TileGather(W, H, 3, rank, world, dev, dist) if world > 1 else None
 
     def stream_ptr():
         return torch.cuda.current_stream().cuda_stream
@@ -126,13 +124,7 @@ def main():
                                  d_dist_ptr=dists.data_ptr() if dists is not None else None)
         if world > 1 and mode == abi.MODE_RENDER:
             # the one exchange step: packed buckets -> rank 0 (peer-to-root sends over xGMI), then untile
-            rc = lib.frayhip_pack_buckets_device(frame.data_ptr(), packed.data_ptr(), W, H, 3, rank, world, stream_ptr())
-            assert rc == 0
-            dist.gather(packed, gather_list, dst=0)
-            if rank == 0:
-                for r in range(1, world):
-                    rc = lib.frayhip_unpack_buckets_device(gather_list[r].data_ptr(), frame.data_ptr(), W, H, 3, r, world, stream_ptr())
-                    assert rc == 0
+            gatherer.gather(frame)
         return st
 
     # counters + algorithmic bytes of one frame (instrumented kernels, untimed)

@@ -1,0 +1,75 @@
+"""The N > 1 path on CPU: world_size 2 (and 3) over gloo.  Each rank renders its own buckets -- here
+with the oracle standing in for the GPU, since this checks the partition + pack + gather + unpack
+contract, not the kernels -- and rank 0 must end up with exactly the single-rank frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, SCENES
+
+
+def np_pack(frame, W, H, rank, world, out):
+    f = frame.numpy()
+    C = f.shape[-1]
+    BW = (W - 1) // 48 + 1
+    nb_total = BW * ((H - 1) // 48 + 1)
+    o = out.numpy().reshape(-1, 48, 48, C)
+    for k, b in enumerate(range(rank, nb_total, world)):
+        bx, by = b % BW, b // BW
+        tile = np.zeros((48, 48, C), np.float32)
+        sub = f[by * 48:by * 48 + 48, bx * 48:bx * 48 + 48]
+        tile[:sub.shape[0], :sub.shape[1]] = sub
+        o[k] = tile
+
+
+def np_unpack(packed, frame, W, H, rank, world):
+    f = frame.numpy()
+    C = f.shape[-1]
+    BW = (W - 1) // 48 + 1
+    nb_total = BW * ((H - 1) // 48 + 1)
+    p = packed.numpy().reshape(-1, 48, 48, C)
+    for k, b in enumerate(range(rank, nb_total, world)):
+        bx, by = b % BW, b // BW
+        sub = f[by * 48:by * 48 + 48, bx * 48:bx * 48 + 48]
+        sub[...] = p[k][:sub.shape[0], :sub.shape[1]]
+
+
+def worker(rank, world, port, W, H, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import fray_amd
+    from fray_amd import abi, tiles
+    from oracle.oracle import Oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = fray_amd.Scene.parseScene(os.path.join(SCENES, "cornell_box.fray"))
+    s.settings.frameWidth, s.settings.frameHeight, s.settings.numPaths = W, H, 2
+    orc = Oracle(abi)
+    mine, st = orc.render(s.desc, abi.MODE_RENDER, seed=42, bucket_first=rank, bucket_stride=world, threads=2)
+    frame = torch.from_numpy(mine.copy())
+    tg = tiles.TileGather(W, H, 3, rank, world, "cpu", dist, pack=np_pack, unpack=np_unpack)
+    tg.gather(frame)
+    rays = torch.tensor([float(st["closest_rays"] + st["shadow_rays"])], dtype=torch.float64)
+    dist.all_reduce(rays)
+    if rank == 0:
+        full, fst = orc.render(s.desc, abi.MODE_RENDER, seed=42, threads=2)
+        np.save(os.path.join(outdir, "ok.npy"), np.array([np.array_equal(frame.numpy(), full),
+                                                          float(rays[0]) == fst["closest_rays"] + fst["shadow_rays"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H", [(2, 200, 130), (3, 97, 101)])
+def test_bucket_shards_gather_to_the_single_rank_frame(tmp_path, world, W, H):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(worker, args=(world, port, W, H, str(tmp_path)), nprocs=world, join=True)
+    ok = np.load(os.path.join(str(tmp_path), "ok.npy"))
+    assert ok[0] == 1 and ok[1] == 1

@@ -174,6 +174,13 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         nodes[i].geomIndex = d.geoms[n.geom].index;
         nodes[i].shader = n.shader;
         nodes[i].bumpTex = n.bump_tex;
+        nodes[i].xfClass = i;
+        nodes[i].pad = 0;
+        for (int j = 0; j < i; j++)
+            if (!memcmp(d.nodes[j].T.offset, n.T.offset, sizeof n.T.offset) && !memcmp(d.nodes[j].T.invM, n.T.invM, sizeof n.T.invM)) {
+                nodes[i].xfClass = nodes[j].xfClass;
+                break;
+            }
         int sk = d.shaders[n.shader].kind;
         if (sk == FRAYHIP_SHADER_REFL || sk == FRAYHIP_SHADER_REFR || sk == FRAYHIP_SHADER_LAYERED) sc->whittedNeedsRecursion = true;
     }
@@ -310,33 +317,33 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     }
     unsigned char* base = (unsigned char*)sc->d_arena;
     for (int mi = 0; mi < d.n_meshes; mi++) {
-        meshes[mi].tris = (const DTri*)(base + moff[mi].tris);
-        meshes[mi].attrs = (const DTriAttr*)(base + moff[mi].attrs);
-        meshes[mi].kd = (const DKd*)(base + moff[mi].kd);
-        meshes[mi].refs = (const int32_t*)(base + moff[mi].refs);
+        meshes[mi].tris = (const FRAY_RO DTri*)(base + moff[mi].tris);
+        meshes[mi].attrs = (const FRAY_RO DTriAttr*)(base + moff[mi].attrs);
+        meshes[mi].kd = (const FRAY_RO DKd*)(base + moff[mi].kd);
+        meshes[mi].refs = (const FRAY_RO int32_t*)(base + moff[mi].refs);
     }
     if (!meshes.empty()) memcpy(A.host.data() + oMeshes, meshes.data(), meshes.size() * sizeof(DMesh));
-    for (int i = 0; i < d.n_textures; i++) tex[i].texels = (const float*)(base + oTexels) + d.textures[i].texel_offset;
+    for (int i = 0; i < d.n_textures; i++) tex[i].texels = (const FRAY_RO float*)(base + oTexels) + d.textures[i].texel_offset;
     if (!tex.empty()) memcpy(A.host.data() + oTex, tex.data(), tex.size() * sizeof(DTexture));
     hipError_t e = hipMemcpy(sc->d_arena, A.host.data(), A.host.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { set_error(std::string("frayhip_scene_create: upload failed: ") + hipGetErrorString(e)); hipFree(sc->d_arena); delete sc; return FRAYHIP_E_NODEVICE; }
     sc->arena_bytes = A.host.size();
 
     DScene& S = sc->S;
-    S.nodes = (const DNode*)(base + oNodes);
-    S.planes = (const DPlane*)(base + oPlanes);
-    S.spheres = (const DSphere*)(base + oSpheres);
-    S.meshes = (const DMesh*)(base + oMeshes);
-    S.shaders = (const DShader*)(base + oShaders);
-    S.layers = (const DLayer*)(base + oLayers);
-    S.textures = (const DTexture*)(base + oTex);
-    S.lights = (const DLight*)(base + oLights);
+    S.nodes = (const FRAY_RO DNode*)(base + oNodes);
+    S.planes = (const FRAY_RO DPlane*)(base + oPlanes);
+    S.spheres = (const FRAY_RO DSphere*)(base + oSpheres);
+    S.meshes = (const FRAY_RO DMesh*)(base + oMeshes);
+    S.shaders = (const FRAY_RO DShader*)(base + oShaders);
+    S.layers = (const FRAY_RO DLayer*)(base + oLayers);
+    S.textures = (const FRAY_RO DTexture*)(base + oTex);
+    S.lights = (const FRAY_RO DLight*)(base + oLights);
     S.env.present = d.environment.present;
     S.env.loaded = d.environment.loaded;
     for (int f = 0; f < 6; f++) {
         S.env.width[f] = d.environment.width[f];
         S.env.height[f] = d.environment.height[f];
-        S.env.face[f] = (const float*)(base + oTexels) + d.environment.texel_offset[f];
+        S.env.face[f] = (const FRAY_RO float*)(base + oTexels) + d.environment.texel_offset[f];
     }
     S.nNodes = d.n_nodes;
     S.nLights = d.n_lights;

@@ -6,12 +6,16 @@
 #include <hip/hip_runtime.h>
 
 #define FD __device__ __forceinline__
+#include "dev_scene.hpp"
 
 struct V3 { double x, y, z; };
 struct C3 { float r, g, b; };
 
 FD V3 v3(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 FD V3 ld3(const double* p) { return v3(p[0], p[1], p[2]); }
+#ifdef __HIP_DEVICE_COMPILE__
+FD V3 ld3(const FRAY_RO double* p) { return v3(p[0], p[1], p[2]); }
+#endif
 FD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 FD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 FD V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
@@ -40,7 +44,8 @@ FD void orthonormalSystem(V3 a, V3& b, V3& c)                           // vecto
     c = cross(a, b);
 }
 // v * M, row-vector convention (matrix.h:36-45); m is row-major 3x3.
-FD V3 mulM(V3 v, const double* m)
+template <class P>
+FD V3 mulM(V3 v, P m)
 {
     return v3(v.x * m[0] + v.y * m[3] + v.z * m[6], v.x * m[1] + v.y * m[4] + v.z * m[7],
               v.x * m[2] + v.y * m[5] + v.z * m[8]);
@@ -48,6 +53,9 @@ FD V3 mulM(V3 v, const double* m)
 
 FD C3 c3(float r, float g, float b) { C3 c; c.r = r; c.g = g; c.b = b; return c; }
 FD C3 ldc(const float* p) { return c3(p[0], p[1], p[2]); }
+#ifdef __HIP_DEVICE_COMPILE__
+FD C3 ldc(const FRAY_RO float* p) { return c3(p[0], p[1], p[2]); }
+#endif
 FD C3 operator+(C3 a, C3 b) { return c3(a.r + b.r, a.g + b.g, a.b + b.b); }
 FD C3 operator-(C3 a, C3 b) { return c3(a.r - b.r, a.g - b.g, a.b - b.b); }
 FD C3 operator*(C3 a, C3 b) { return c3(a.r * b.r, a.g * b.g, a.b * b.b); }

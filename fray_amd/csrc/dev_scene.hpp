@@ -15,12 +15,24 @@
 #pragma once
 #include <stdint.h>
 
+// Scene tables are read-only for the whole frame.  On the device their pointers are typed into the
+// constant address space (4): loads through them are known not to alias the kernels' stores, so a
+// wave-uniform access (node loop, brute-force triangle loop, light / shader tables) becomes a
+// scalar-cache s_load into SGPRs instead of a 64-lane vector load, and the compiler may batch them.
+#ifdef __HIP_DEVICE_COMPILE__
+#define FRAY_RO __attribute__((address_space(4)))
+#else
+#define FRAY_RO
+#endif
+
 struct DXform { double off[3]; double m[9]; double inv[9]; };
 
 struct DNode {
     DXform T;
     int32_t geomKind, geomIndex, shader, bumpTex;
-};
+    int32_t xfClass;      // index of the first node whose {offset, invM} is bitwise equal: nodes of one
+    int32_t pad;          // class see the same local ray, so it is computed once per ray (e.g. the 7
+};                        // untransformed Cornell-box meshes)
 
 struct DPlane { double limit, height; };
 struct DSphere { double O[3]; double R; };
@@ -47,10 +59,10 @@ struct DKd {           // 48 B
 
 struct DMesh {
     double bmin[3], bmax[3];
-    const DTri* tris;
-    const DTriAttr* attrs;
-    const DKd* kd;
-    const int32_t* refs;
+    const FRAY_RO DTri* tris;
+    const FRAY_RO DTriAttr* attrs;
+    const FRAY_RO DKd* kd;
+    const FRAY_RO int32_t* refs;
     int32_t nTris, hasKd, smooth, culling, hasUV, pad;
 };
 
@@ -58,7 +70,7 @@ struct DTexture {
     int32_t kind, width, height, pad;
     float color1[3], color2[3];
     double scaling, bumpIntensity, ior;
-    const float* texels;
+    const FRAY_RO float* texels;
 };
 
 struct DShader {
@@ -84,7 +96,7 @@ struct DLight {
 struct DEnv {
     int32_t present, loaded;
     int32_t width[6], height[6];
-    const float* face[6];
+    const FRAY_RO float* face[6];
 };
 
 // Per-frame camera state, Camera::beginFrame (camera.cpp:34-57), computed on the host.
@@ -97,14 +109,14 @@ struct DCamera {
 };
 
 struct DScene {
-    const DNode* nodes;
-    const DPlane* planes;
-    const DSphere* spheres;
-    const DMesh* meshes;
-    const DShader* shaders;
-    const DLayer* layers;
-    const DTexture* textures;
-    const DLight* lights;
+    const FRAY_RO DNode* nodes;
+    const FRAY_RO DPlane* planes;
+    const FRAY_RO DSphere* spheres;
+    const FRAY_RO DMesh* meshes;
+    const FRAY_RO DShader* shaders;
+    const FRAY_RO DLayer* layers;
+    const FRAY_RO DTexture* textures;
+    const FRAY_RO DLight* lights;
     DEnv env;
     int32_t nNodes, nLights;
     float ambient[3];

@@ -20,7 +20,7 @@ struct HitInfo {           // IntersectionInfo, geometry.h:33-39 (after Node::in
 // result only textures and bump maps read.
 FD void finalize_hit(const DScene& S, const HitRec& h, V3 o, V3 d, bool needUV, HitInfo& info)
 {
-    const DNode& N = S.nodes[h.node];
+    const FRAY_RO DNode& N = S.nodes[h.node];
     V3 ls = mulM(o - ld3(N.T.off), N.T.inv);
     V3 ldir = normalized(mulM(d, N.T.inv));
     V3 ipl = ls + ldir * h.t;
@@ -33,15 +33,15 @@ FD void finalize_hit(const DScene& S, const HitRec& h, V3 o, V3 d, bool needUV, 
         info.u = ipl.x;
         info.v = ipl.z;
     } else if (N.geomKind == 1) {
-        const DSphere& Sp = S.spheres[N.geomIndex];
+        const FRAY_RO DSphere& Sp = S.spheres[N.geomIndex];
         nl = normalized(ipl - ld3(Sp.O));
         if (needUV) {
             info.u = ((atan2(nl.z, nl.x) / FRAY_PI * 180.0) + 180.0) / 360.0;
             info.v = 1 - ((asin(nl.y) / FRAY_PI * 180.0) + 90) / 180.0;
         }
     } else {
-        const DMesh& M = S.meshes[N.geomIndex];
-        const DTriAttr* A = M.attrs + h.tri;
+        const FRAY_RO DMesh& M = S.meshes[N.geomIndex];
+        const FRAY_RO DTriAttr* A = M.attrs + h.tri;
         if (M.smooth) {
             V3 nA = ld3(A->nA), nB = ld3(A->nB), nC = ld3(A->nC);
             nl = normalized(nA + (nB - nA) * h.l2 + (nC - nA) * h.l3);
@@ -61,13 +61,13 @@ FD void finalize_hit(const DScene& S, const HitRec& h, V3 o, V3 d, bool needUV, 
 
 // ---- textures -----------------------------------------------------------------------------------
 template <bool ST>
-FD C3 texel(const DTexture& T, int x, int y, Cnt& c)   // Bitmap::getPixel, bitmap.cpp:67-71
+FD C3 texel(const FRAY_RO DTexture& T, int x, int y, Cnt& c)   // Bitmap::getPixel, bitmap.cpp:67-71
 {
     bump<ST>(c.tex);
     if (T.width <= 0 || x < 0 || x >= T.width || y < 0 || y >= T.height) return c3(0, 0, 0);
     return ldc(T.texels + 3 * ((long long)x + (long long)y * T.width));
 }
-FD void wrap_texel(const DTexture& T, double u, double v, int& ix, int& iy)   // shading.cpp:149-155, 404-410
+FD void wrap_texel(const FRAY_RO DTexture& T, double u, double v, int& ix, int& iy)   // shading.cpp:149-155, 404-410
 {
     ix = int(floor(u * T.scaling * T.width));
     iy = int(floor(v * T.scaling * T.height));
@@ -86,7 +86,7 @@ FD float fresnel_schlick(V3 i, V3 n, float ior)   // shading.cpp:230-236
 template <bool ST>
 FD C3 texture_sample(const DScene& S, int t, V3 rayDir, const HitInfo& info, Cnt& c)
 {
-    const DTexture& T = S.textures[t];
+    const FRAY_RO DTexture& T = S.textures[t];
     if (T.kind == 0) {   // CheckerTexture::sample, shading.cpp:40-46
         int ix = int(floor(info.u * T.scaling) / 5.0);
         int iy = int(floor(info.v * T.scaling) / 5.0);
@@ -113,7 +113,7 @@ FD void apply_bump(const DScene& S, int nodeIdx, HitInfo& info, Cnt& c)
 {
     int bt = S.nodes[nodeIdx].bumpTex;
     if (bt < 0) return;
-    const DTexture& T = S.textures[bt];
+    const FRAY_RO DTexture& T = S.textures[bt];
     if (T.kind != 2) return;
     int ix, iy;
     wrap_texel(T, info.u, info.v, ix, iy);
@@ -154,10 +154,10 @@ FD C3 environment(const DScene& S, V3 dir, Cnt& c)
 }
 
 // ---- lights (lights.h:41-47, lights.cpp:31-77,105-108) ---------------------------------------------
-FD int light_num_samples(const DLight& L) { return L.kind == 0 ? 1 : L.xSubd * L.ySubd; }
-FD C3 light_color(const DLight& L) { return ldc(L.color) * L.power; }
+FD int light_num_samples(const FRAY_RO DLight& L) { return L.kind == 0 ? 1 : L.xSubd * L.ySubd; }
+FD C3 light_color(const FRAY_RO DLight& L) { return ldc(L.color) * L.power; }
 template <class G>
-FD void light_nth_sample(const DLight& L, int idx, V3 shadePos, G& tab, V3& samplePos, C3& color)
+FD void light_nth_sample(const FRAY_RO DLight& L, int idx, V3 shadePos, G& tab, V3& samplePos, C3& color)
 {
     if (L.kind == 0) {
         samplePos = ld3(L.pos);
@@ -182,7 +182,7 @@ FD void light_nth_sample(const DLight& L, int idx, V3 shadePos, G& tab, V3& samp
     }
     samplePos = mulM(pointOnLight, L.T.m) + ld3(L.T.off);
 }
-FD double light_solid_angle(const DLight& L, V3 ip)
+FD double light_solid_angle(const FRAY_RO DLight& L, V3 ip)
 {
     if (L.kind == 0) return 0;
     double q = lengthSqr(ip - ld3(L.center));
@@ -191,14 +191,14 @@ FD double light_solid_angle(const DLight& L, V3 ip)
 
 // ---- Whitted: Lambert::shade / Phong::shade (shading.cpp:48-80, 101-144) ---------------------------
 template <bool ST, class G>
-FD C3 shade_direct(const DScene& S, const DShader& sh, V3 rayDir, const HitInfo& info, G& tab, bool phong, Cnt& c)
+FD C3 shade_direct(const DScene& S, const FRAY_RO DShader& sh, V3 rayDir, const HitInfo& info, G& tab, bool phong, Cnt& c)
 {
     C3 diffuse = ldc(sh.color);
     if (sh.texture >= 0) diffuse = diffuse * texture_sample<ST>(S, sh.texture, rayDir, info, c);
     C3 result = diffuse * ldc(S.ambient);
     const int nl = S.nLights;
     for (int li = 0; li < nl; li++) {
-        const DLight& L = S.lights[li];
+        const FRAY_RO DLight& L = S.lights[li];
         const int ns = light_num_samples(L);
         C3 sum = c3(0, 0, 0);
         for (int k = 0; k < ns; k++) {
@@ -239,7 +239,7 @@ FD V3 hemisphere_sample(Mt& tab, V3 norm)   // main.cpp:92-116
     if (dot(dir, norm) > 0) return dir;
     return -dir;
 }
-FD C3 brdf_eval(const DShader& sh, const HitInfo& x, V3 w_out)
+FD C3 brdf_eval(const FRAY_RO DShader& sh, const HitInfo& x, V3 w_out)
 {
     if (sh.kind == 1) {   // Lambert::eval, shading.cpp:82-86
         double dd = dot(x.norm, w_out);
@@ -250,11 +250,11 @@ FD C3 brdf_eval(const DShader& sh, const HitInfo& x, V3 w_out)
     return c3(1, 0, 0);                                     // Shader::eval default, shading.h:124-127
 }
 // Number of table-generator words the discarded first spawnRay consumes (main.cpp:219-224).
-FD int spawn_words(const DShader& sh) { return sh.kind == 1 ? 4 : 0; }
+FD int spawn_words(const FRAY_RO DShader& sh) { return sh.kind == 1 ? 4 : 0; }
 
 struct PathRay { V3 o, d; int depth; unsigned flags; };
 
-FD void spawn_ray(const DShader& sh, const HitInfo& x, const PathRay& w_in, Mt& tab, PathRay& w_out, C3& brdf, float& pdf)
+FD void spawn_ray(const FRAY_RO DShader& sh, const HitInfo& x, const PathRay& w_in, Mt& tab, PathRay& w_out, C3& brdf, float& pdf)
 {
     w_out = w_in;
     if (sh.kind == 1) {   // Lambert::spawnRay, shading.cpp:88-99
@@ -306,11 +306,11 @@ FD void spawn_ray(const DShader& sh, const HitInfo& x, const PathRay& w_in, Mt& 
 // explicitLightSample, main.cpp:118-169.  `rnd` is the worker's local generator, `tab` the
 // per-thread table generator (RectLight::getNthSample draws from the latter).
 template <bool ST>
-FD C3 explicit_light_sample(const DScene& S, V3 rayDir, const HitInfo& info, C3 pm, const DShader& sh, Mt& rnd, Mt& tab, Cnt& c)
+FD C3 explicit_light_sample(const DScene& S, V3 rayDir, const HitInfo& info, C3 pm, const FRAY_RO DShader& sh, Mt& rnd, Mt& tab, Cnt& c)
 {
     if (S.nLights == 0) return c3(0, 0, 0);
     int lightIdx = rng_int0(rnd, S.nLights - 1);
-    const DLight& L = S.lights[lightIdx];
+    const FRAY_RO DLight& L = S.lights[lightIdx];
     V3 x = info.ip;
     double solidAngle = light_solid_angle(L, x);
     if (solidAngle == 0) return c3(0, 0, 0);

@@ -81,7 +81,7 @@ FD void box_set_lo(Box6& b, int axis, double v) { if (axis == 0) b.lox = v; else
 // test part only.  `best` is info.dist: accepted when gamma <= best, so the LAST equal-distance
 // triangle in visiting order wins, as in the reference.
 template <bool ST>
-FD bool tri_test(const DTri* T, int culling, V3 s, V3 d, double& best, double& l2o, double& l3o, Cnt& c)
+FD bool tri_test(const FRAY_RO DTri* T, int culling, V3 s, V3 d, double& best, double& l2o, double& l3o, Cnt& c)
 {
     bump<ST>(c.tri);
     if (culling && dot(d, ld3(T->g)) > 0) return false;
@@ -107,7 +107,7 @@ FD bool tri_test(const DTri* T, int culling, V3 s, V3 d, double& best, double& l
 
 // Mesh::intersect (mesh.cpp:144-165).  On true: gamma / tri / l2 / l3 describe info.
 template <bool ST>
-FD bool mesh_intersect(const DMesh& M, V3 s, V3 d, double& gamma, int& tri, double& l2, double& l3, Cnt& c)
+FD bool mesh_intersect(const FRAY_RO DMesh& M, V3 s, V3 d, double& gamma, int& tri, double& l2, double& l3, Cnt& c)
 {
     V3 rd;   // RRay::prepareForTracing, bbox.h:49-54
     rd.x = fabs(d.x) > 1e-12 ? 1.0 / d.x : 1e12;
@@ -127,7 +127,7 @@ FD bool mesh_intersect(const DMesh& M, V3 s, V3 d, double& gamma, int& tri, doub
         return found;
     }
     // ---- stackless KD walk (Mesh::intersectKD, mesh.cpp:357-394) ----
-    const DKd* kd = M.kd;
+    const FRAY_RO DKd* kd = M.kd;
     int node = 0;
     bool down = true;          // true: entering `node`; false: leaving it upwards
     for (;;) {
@@ -180,11 +180,11 @@ FD bool mesh_intersect(const DMesh& M, V3 s, V3 d, double& gamma, int& tri, doub
 // Geometry part of Node::intersect for node N on the local ray; on a hit returns the local
 // intersection point and fills t / tri / l2 / l3.
 template <bool ST>
-FD bool geom_intersect(const DScene& S, const DNode& N, V3 ls, V3 ld, V3& ipl, double& t, int& tri, double& l2, double& l3, Cnt& c)
+FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, V3 ls, V3 ld, V3& ipl, double& t, int& tri, double& l2, double& l3, Cnt& c)
 {
     if (N.geomKind == 0) {   // Plane::intersect, geometry.cpp:30-50
         bump<ST>(c.prim);
-        const DPlane P = S.planes[N.geomIndex];
+        const FRAY_RO DPlane& P = S.planes[N.geomIndex];
         if (ls.y > P.height && ld.y >= 0) return false;
         if (ls.y < P.height && ld.y <= 0) return false;
         double travelByY = fabs(ls.y - P.height);
@@ -199,7 +199,7 @@ FD bool geom_intersect(const DScene& S, const DNode& N, V3 ls, V3 ld, V3& ipl, d
     }
     if (N.geomKind == 1) {   // Sphere::intersect, geometry.cpp:52-83
         bump<ST>(c.prim);
-        const DSphere Sp = S.spheres[N.geomIndex];
+        const FRAY_RO DSphere& Sp = S.spheres[N.geomIndex];
         V3 H = ls - ld3(Sp.O);
         double A = 1;
         double B = 2 * dot(ld, H);
@@ -218,7 +218,7 @@ FD bool geom_intersect(const DScene& S, const DNode& N, V3 ls, V3 ld, V3& ipl, d
         return true;
     }
     // mesh
-    const DMesh& M = S.meshes[N.geomIndex];
+    const FRAY_RO DMesh& M = S.meshes[N.geomIndex];
     double gamma;
     if (!mesh_intersect<ST>(M, ls, ld, gamma, tri, l2, l3, c)) return false;
     ipl = ls + ld * gamma;
@@ -226,16 +226,23 @@ FD bool geom_intersect(const DScene& S, const DNode& N, V3 ls, V3 ld, V3& ipl, d
     return true;
 }
 
+// Local ray of a node (Transform::untransformPoint / untransformDir, matrix.cpp:148-161), cached per
+// transform class: nodes whose {offset, invM} are bitwise identical yield the same local ray.
+struct LocalRay { V3 s, d; int cls; };
+
 // Node::intersect (geometry.cpp:196-208) reduced to what the closest-hit comparison needs.
 template <bool ST>
-FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, double& dist, double& t, int& tri, double& l2, double& l3, Cnt& c)
+FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double& dist, double& t, int& tri, double& l2, double& l3, Cnt& c)
 {
     bump<ST>(c.node);
-    const DNode& N = S.nodes[i];
-    V3 ls = mulM(o - ld3(N.T.off), N.T.inv);
-    V3 ldir = normalized(mulM(d, N.T.inv));
+    const FRAY_RO DNode& N = S.nodes[i];
+    if (N.xfClass != lr.cls) {
+        lr.s = mulM(o - ld3(N.T.off), N.T.inv);
+        lr.d = normalized(mulM(d, N.T.inv));
+        lr.cls = N.xfClass;
+    }
     V3 ipl;
-    if (!geom_intersect<ST>(S, N, ls, ldir, ipl, t, tri, l2, l3, c)) return false;
+    if (!geom_intersect<ST>(S, N, lr.s, lr.d, ipl, t, tri, l2, l3, c)) return false;
     V3 ipw = mulM(ipl, N.T.m) + ld3(N.T.off);
     dist = length(o - ipw);
     return true;
@@ -243,7 +250,7 @@ FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, double& dist, double&
 
 // RectLight::intersect (lights.cpp:79-103); point lights are never hit (lights.h:68-71).
 template <bool ST>
-FD bool light_intersect(const DLight& L, V3 o, V3 d, double& dist, Cnt& c)
+FD bool light_intersect(const FRAY_RO DLight& L, V3 o, V3 d, double& dist, Cnt& c)
 {
     if (L.kind == 0) return false;
     bump<ST>(c.prim);
@@ -271,15 +278,17 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitRec& best, Cnt& c)
     best.dist = 1e99;
     best.t = 0; best.l2 = 0; best.l3 = 0;
     const int nn = S.nNodes;
+    LocalRay lr;
+    lr.cls = -1;
     for (int i = 0; i < nn; i++) {
         double dist, t, l2 = 0, l3 = 0;
         int tri = -1;
-        if (node_intersect<ST>(S, i, o, d, dist, t, tri, l2, l3, c) && dist < best.dist) {
+        if (node_intersect<ST>(S, i, o, d, lr, dist, t, tri, l2, l3, c) && dist < best.dist) {
             best.node = i; best.tri = tri; best.dist = dist; best.t = t; best.l2 = l2; best.l3 = l3;
         }
     }
     if (ST && best.node >= 0) {   // byte model: the winner's corner normals / uvs
-        const DNode& W = S.nodes[best.node];
+        const FRAY_RO DNode& W = S.nodes[best.node];
         if (W.geomKind == 3 && S.meshes[W.geomIndex].smooth) c.smooth++;
     }
     const int nl = S.nLights;
@@ -302,10 +311,12 @@ FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c)
     double maxDist = length(a - b);
     d = normalized(d);
     const int nn = S.nNodes;
+    LocalRay lr;
+    lr.cls = -1;
     for (int i = 0; i < nn; i++) {
         double dist, t, l2, l3;
         int tri;
-        if (node_intersect<ST>(S, i, a, d, dist, t, tri, l2, l3, c) && dist < maxDist) return false;
+        if (node_intersect<ST>(S, i, a, d, lr, dist, t, tri, l2, l3, c) && dist < maxDist) return false;
     }
     return true;
 }

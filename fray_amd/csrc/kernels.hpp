@@ -81,8 +81,8 @@ FD C3 raytrace_flat(const DScene& S, V3 o, V3 d, G& tab, Cnt& c)
     closest_hit<ST>(S, o, d, h, c);
     if (h.node <= -2) return light_color(S.lights[-2 - h.node]);
     if (h.node < 0) return environment<ST>(S, d, c);
-    const DNode& N = S.nodes[h.node];
-    const DShader& sh = S.shaders[N.shader];
+    const FRAY_RO DNode& N = S.nodes[h.node];
+    const FRAY_RO DShader& sh = S.shaders[N.shader];
     HitInfo info;
     finalize_hit(S, h, o, d, sh.usesUV || N.bumpTex >= 0, info);
     apply_bump<ST>(S, h.node, info, c);
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(256) void k_pt_bounce(DScene S, PathQueue Qin, Path
             } else if (h.node < 0) {                                  // main.cpp:210-215
                 path_finish(sampleRad, st, ps, environment<ST>(S, ps.d, c) * ps.pm);
             } else {
-                const DNode& N = S.nodes[h.node];
-                const DShader& sh = S.shaders[N.shader];
+                const FRAY_RO DNode& N = S.nodes[h.node];
+                const FRAY_RO DShader& sh = S.shaders[N.shader];
                 HitInfo info;
                 finalize_hit(S, h, ps.o, ps.d, sh.usesUV || N.bumpTex >= 0, info);
                             apply_bump<ST>(S, h.node, info, c);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstddef>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -57,7 +58,7 @@ struct frayhip_scene {
     void* d_work = nullptr;
     size_t work_bytes = 0;
     DStats* d_stats = nullptr;
-    uint32_t* d_qcount = nullptr;     // [64] queue sizes per bounce
+    QMeta* d_qmeta = nullptr;         // [2] segment tables of the ping-pong path queues
     hipEvent_t evA = nullptr, evB = nullptr;
     std::vector<hipEvent_t> evPool;
 };
@@ -350,7 +351,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     sc->camera = d.camera;
     sc->settings = d.settings;
     hipMalloc((void**)&sc->d_stats, sizeof(DStats));
-    hipMalloc((void**)&sc->d_qcount, 64 * sizeof(uint32_t));
+    hipMalloc((void**)&sc->d_qmeta, 2 * sizeof(QMeta));
     hipEventCreate(&sc->evA);
     hipEventCreate(&sc->evB);
     *out = sc;
@@ -363,7 +364,7 @@ void frayhip_scene_destroy(frayhip_scene* s)
     if (s->d_arena) hipFree(s->d_arena);
     if (s->d_work) hipFree(s->d_work);
     if (s->d_stats) hipFree(s->d_stats);
-    if (s->d_qcount) hipFree(s->d_qcount);
+    if (s->d_qmeta) hipFree(s->d_qmeta);
     if (s->evA) hipEventDestroy(s->evA);
     if (s->evB) hipEventDestroy(s->evB);
     for (auto e : s->evPool) hipEventDestroy(e);
@@ -457,13 +458,17 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             if (sc->whittedNeedsRecursion) { set_error("frayhip_render: Whitted recursion (Refl / Refr / Layered) is not implemented on the device path yet"); return FRAYHIP_E_UNSUPPORTED; }
             if (!F.jitter && spp > 5) { set_error("frayhip_render: bad sample count"); return FRAYHIP_E_ARG; }
             if (nItems > 0) {
-                // per-thread mt19937 state columns for samples that draw more than 227 words
+                // workspace: per-thread mt19937 state columns for samples that draw more than 227 words,
+                // then x[397] of every (pixel, sample) seed
                 const int grid = grid_for(nItems);
-                int rc = ensure_work(sc, (size_t)grid * 256 * 624 * sizeof(uint32_t));
+                const size_t colBytes = ((size_t)grid * 256 * 624 * sizeof(uint32_t) + 255) / 256 * 256;
+                int rc = ensure_work(sc, colBytes + (size_t)nItems * spp * sizeof(uint32_t));
                 if (rc) return rc;
+                uint32_t* x397 = (uint32_t*)((unsigned char*)sc->d_work + colBytes);
+                hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * spp + 3) / 4)), dim3(256), 0, stream, F, nItems, 0, spp, x397);
                 hipEvent_t a = pool_event(sc, 0), b = pool_event(sc, 1);
                 HIP_TRY(hipEventRecord(a, stream));
-                hipLaunchKernelGGL(k_whitted<ST>, dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, sc->d_stats);
+                hipLaunchKernelGGL(k_whitted<ST>, dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats);
                 HIP_TRY(hipEventRecord(b, stream));
                 nTraceEvents = 2;
             }
@@ -472,28 +477,37 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, ((size_t)1 << 26) / (size_t)nItems);
             if (chunk > spp) chunk = spp;
             const size_t nPaths = (size_t)nItems * chunk;
-            const size_t need = 2 * queue_bytes(nPaths) + nPaths * 12 + (size_t)nItems * 12 + 4096;
+            const size_t nQueue = nPaths + (size_t)FRAY_MAXSEG * 128;   // per-wave segments round their share up to 64
+            const size_t need = 2 * queue_bytes(nQueue) + nPaths * 12 + (size_t)nItems * 12 + nPaths * 4 + 8192;
             int rc = ensure_work(sc, need);
             if (rc) return rc;
             PathQueue Q[2];
             unsigned char* p = (unsigned char*)sc->d_work;
-            p = carve_queue(p, nPaths, Q[0]);
-            p = carve_queue(p, nPaths, Q[1]);
+            p = carve_queue(p, nQueue, Q[0]);
+            p = carve_queue(p, nQueue, Q[1]);
             float* sampleRad = (float*)p; p += (nPaths * 12 + 255) / 256 * 256;
-            float* sum = (float*)p;
+            float* sum = (float*)p; p += ((size_t)nItems * 12 + 255) / 256 * 256;
+            uint32_t* x397 = (uint32_t*)p;
             const int nBounce = set.maxTraceDepth + 2;
             for (int s0 = 0; s0 < spp; s0 += chunk) {
                 const int cn = std::min(chunk, spp - s0);
-                HIP_TRY(hipMemsetAsync(sc->d_qcount, 0, 64 * sizeof(uint32_t), stream));
+                // queue 0 is dense: one segment holding every slot of the batch
+                QMeta head{};
+                head.n = (uint32_t)((size_t)nItems * cn); head.chunk = head.n; head.nSeg = 1;
+                HIP_TRY(hipMemcpyAsync(sc->d_qmeta, &head, 16, hipMemcpyHostToDevice, stream));
+                const uint32_t offs[2] = {0u, head.n};
+                HIP_TRY(hipMemcpyAsync((unsigned char*)sc->d_qmeta + offsetof(QMeta, off), offs, sizeof offs, hipMemcpyHostToDevice, stream));
+                hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * cn + 3) / 4)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
                 hipLaunchKernelGGL(k_pt_init<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, C, F, nItems, s0, cn, Q[0],
-                                   sc->d_qcount, sampleRad, sc->d_stats);
+                                   sampleRad, x397, sc->d_stats);
                 for (int b = 0; b < nBounce; b++) {
                     hipEvent_t ea = pool_event(sc, nTraceEvents), eb = pool_event(sc, nTraceEvents + 1);
                     HIP_TRY(hipEventRecord(ea, stream));
                     hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, Q[b & 1], Q[(b + 1) & 1],
-                                       sc->d_qcount + b, sc->d_qcount + b + 1, sampleRad, sc->d_stats);
+                                       sc->d_qmeta + (b & 1), sc->d_qmeta + ((b + 1) & 1), sampleRad, sc->d_stats);
                     HIP_TRY(hipEventRecord(eb, stream));
                     nTraceEvents += 2;
+                    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, sc->d_qmeta + ((b + 1) & 1));
                 }
                 hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, stream, F, nItems, s0, cn, sampleRad, sum, d_rgb);
             }

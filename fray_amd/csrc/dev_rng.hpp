@@ -28,6 +28,17 @@ FD Mt mt_seed(uint32_t s)
     return r;
 }
 
+// Same, with x[397] already known (k_seed computes it for a whole batch, four independent chains
+// per lane, because the 397-step recurrence is one long dependency chain).
+FD Mt mt_seed_with(uint32_t s, uint32_t x397)
+{
+    Mt r;
+    r.j = 0;
+    r.a = s;
+    r.b = x397;
+    return r;
+}
+
 FD uint32_t mt_next(Mt& r)
 {
     uint32_t a1 = mt_lcg(r.a, r.j + 1);
@@ -117,6 +128,7 @@ struct MtLong {
     int idx;            // next output position in the materialised state, -1 = not materialised
 
     FD void reseed(uint32_t s) { r = mt_seed(s); seed = s; idx = -1; }
+    FD void reseed_with(uint32_t s, uint32_t x397) { r = mt_seed_with(s, x397); seed = s; idx = -1; }
     FD uint32_t& w(int k) { return st[(size_t)k * stride]; }
     FD static uint32_t tw(uint32_t u, uint32_t v)
     {

@@ -30,6 +30,11 @@ struct HitRec {
 
 struct Box6 { double lox, loy, loz, hix, hiy, hiz; };
 
+// Local ray of a node (Transform::untransformPoint / untransformDir, matrix.cpp:148-161), cached per
+// transform class: nodes whose {offset, invM} are bitwise identical yield the same local ray.
+struct LocalRay { V3 s, d, rd; int cls; bool haveRd; };
+
+
 FD bool box_inside(const Box6& b, V3 v)   // BBox::inside, bbox.h:79-84
 {
     return b.lox - 1e-6 <= v.x && v.x <= b.hix + 1e-6 && b.loy - 1e-6 <= v.y && v.y <= b.hiy + 1e-6 &&
@@ -107,12 +112,16 @@ FD bool tri_test(const FRAY_RO DTri* T, int culling, V3 s, V3 d, double& best, d
 
 // Mesh::intersect (mesh.cpp:144-165).  On true: gamma / tri / l2 / l3 describe info.
 template <bool ST>
-FD bool mesh_intersect(const FRAY_RO DMesh& M, V3 s, V3 d, double& gamma, int& tri, double& l2, double& l3, Cnt& c)
+FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int& tri, double& l2, double& l3, Cnt& c)
 {
-    V3 rd;   // RRay::prepareForTracing, bbox.h:49-54
-    rd.x = fabs(d.x) > 1e-12 ? 1.0 / d.x : 1e12;
-    rd.y = fabs(d.y) > 1e-12 ? 1.0 / d.y : 1e12;
-    rd.z = fabs(d.z) > 1e-12 ? 1.0 / d.z : 1e12;
+    const V3 s = lr.s, d = lr.d;
+    if (!lr.haveRd) {   // RRay::prepareForTracing, bbox.h:49-54 -- a function of the local ray only
+        lr.rd.x = fabs(d.x) > 1e-12 ? 1.0 / d.x : 1e12;
+        lr.rd.y = fabs(d.y) > 1e-12 ? 1.0 / d.y : 1e12;
+        lr.rd.z = fabs(d.z) > 1e-12 ? 1.0 / d.z : 1e12;
+        lr.haveRd = true;
+    }
+    const V3 rd = lr.rd;
     Box6 box;
     box.lox = M.bmin[0]; box.loy = M.bmin[1]; box.loz = M.bmin[2];
     box.hix = M.bmax[0]; box.hiy = M.bmax[1]; box.hiz = M.bmax[2];
@@ -180,8 +189,9 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, V3 s, V3 d, double& gamma, int& t
 // Geometry part of Node::intersect for node N on the local ray; on a hit returns the local
 // intersection point and fills t / tri / l2 / l3.
 template <bool ST>
-FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, V3 ls, V3 ld, V3& ipl, double& t, int& tri, double& l2, double& l3, Cnt& c)
+FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, LocalRay& lr, V3& ipl, double& t, int& tri, double& l2, double& l3, Cnt& c)
 {
+    const V3 ls = lr.s, ld = lr.d;
     if (N.geomKind == 0) {   // Plane::intersect, geometry.cpp:30-50
         bump<ST>(c.prim);
         const FRAY_RO DPlane& P = S.planes[N.geomIndex];
@@ -220,15 +230,12 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, V3 ls, V3 ld, V3
     // mesh
     const FRAY_RO DMesh& M = S.meshes[N.geomIndex];
     double gamma;
-    if (!mesh_intersect<ST>(M, ls, ld, gamma, tri, l2, l3, c)) return false;
+    if (!mesh_intersect<ST>(M, lr, gamma, tri, l2, l3, c)) return false;
     ipl = ls + ld * gamma;
     t = gamma;
     return true;
 }
 
-// Local ray of a node (Transform::untransformPoint / untransformDir, matrix.cpp:148-161), cached per
-// transform class: nodes whose {offset, invM} are bitwise identical yield the same local ray.
-struct LocalRay { V3 s, d; int cls; };
 
 // Node::intersect (geometry.cpp:196-208) reduced to what the closest-hit comparison needs.
 template <bool ST>
@@ -240,9 +247,10 @@ FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double&
         lr.s = mulM(o - ld3(N.T.off), N.T.inv);
         lr.d = normalized(mulM(d, N.T.inv));
         lr.cls = N.xfClass;
+        lr.haveRd = false;
     }
     V3 ipl;
-    if (!geom_intersect<ST>(S, N, lr.s, lr.d, ipl, t, tri, l2, l3, c)) return false;
+    if (!geom_intersect<ST>(S, N, lr, ipl, t, tri, l2, l3, c)) return false;
     V3 ipw = mulM(ipl, N.T.m) + ld3(N.T.off);
     dist = length(o - ipw);
     return true;
@@ -280,6 +288,7 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitRec& best, Cnt& c)
     const int nn = S.nNodes;
     LocalRay lr;
     lr.cls = -1;
+    lr.haveRd = false;
     for (int i = 0; i < nn; i++) {
         double dist, t, l2 = 0, l3 = 0;
         int tri = -1;
@@ -313,6 +322,7 @@ FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c)
     const int nn = S.nNodes;
     LocalRay lr;
     lr.cls = -1;
+    lr.haveRd = false;
     for (int i = 0; i < nn; i++) {
         double dist, t, l2, l3;
         int tri;

@@ -11,6 +11,10 @@
 #pragma once
 #include "dev_shade.hpp"
 
+#ifndef FRAY_BOUNCE_WAVES
+#define FRAY_BOUNCE_WAVES 3   // waves per SIMD the bounce kernel is register-allocated for (measured: 2 -> 215 ms, 3 -> 183 ms, 4 -> 183 ms)
+#endif
+
 // ---- work item -> pixel ------------------------------------------------------------------------
 FD bool item_pixel(const DFrame& F, int item, int& x, int& y)
 {
@@ -53,6 +57,38 @@ FD void dof_ray(const DCamera& C, double x, double y, G& tab, V3& o, V3& d)
     d = normalized(T - o);
 }
 
+// ---- mt19937 seeding for a batch of camera samples -------------------------------------------------
+// x397[s * nItems + item] = x[397] of the seeding recurrence started at the contract seed of
+// (pixel(item), sample s0 + s).  The recurrence is a 397-long dependency chain of
+// shift / xor / 32-bit multiply / add, so each lane runs four independent chains at once and the
+// kernel keeps its register count low enough for full occupancy.
+__global__ __launch_bounds__(256) void k_seed(DFrame F, int nItems, int s0, int chunk, uint32_t* __restrict__ x397)
+{
+    const uint32_t total = (uint32_t)nItems * (uint32_t)chunk;
+    const uint32_t quads = (total + 3u) / 4u;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x) {
+        uint32_t b[4], slot[4];
+        bool ok[4];
+        for (int k = 0; k < 4; k++) {
+            // strided so that consecutive lanes write consecutive words
+            slot[k] = q + (uint32_t)k * quads;
+            ok[k] = slot[k] < total;
+            b[k] = 0;
+            if (ok[k]) {
+                int item = (int)(slot[k] % (uint32_t)nItems), s = (int)(slot[k] / (uint32_t)nItems);
+                int x, y;
+                ok[k] = item_pixel(F, item, x, y);
+                b[k] = sample_seed(F.seed, (uint32_t)y * (uint32_t)F.W + (uint32_t)x, (uint32_t)(s0 + s));
+            }
+        }
+#pragma unroll 1
+        for (uint32_t i = 1; i <= 397; i++) {
+            b[0] = mt_lcg(b[0], i); b[1] = mt_lcg(b[1], i); b[2] = mt_lcg(b[2], i); b[3] = mt_lcg(b[3], i);
+        }
+        for (int k = 0; k < 4; k++) if (slot[k] < total) x397[slot[k]] = b[k];
+    }
+}
+
 // ---- MODE_PRIMARY_ID ------------------------------------------------------------------------------
 template <bool ST>
 __global__ __launch_bounds__(256) void k_primary(DScene S, DCamera C, DFrame F, int nItems, int32_t* __restrict__ hitId,
@@ -93,7 +129,8 @@ FD C3 raytrace_flat(const DScene& S, V3 o, V3 d, G& tab, Cnt& c)
 __constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0, 0.6}, {0.6, 0.6}};   // main.cpp:55-61
 
 template <bool ST>
-__global__ __launch_bounds__(256) void k_whitted(DScene S, DCamera C, DFrame F, int nItems, float* __restrict__ rgb, uint32_t* mtWork, DStats* st)
+__global__ __launch_bounds__(256) void k_whitted(DScene S, DCamera C, DFrame F, int nItems, float* __restrict__ rgb, uint32_t* mtWork,
+                                                 const uint32_t* __restrict__ x397, DStats* st)
 {
     Cnt c = zero_cnt();
     MtLong tab;
@@ -107,7 +144,7 @@ __global__ __launch_bounds__(256) void k_whitted(DScene S, DCamera C, DFrame F, 
         bool ovf = false;
         for (int i = 0; i < F.spp; i++) {
             const uint32_t sd = sample_seed(F.seed, p, (uint32_t)i);
-            tab.reseed(sd);
+            tab.reseed_with(sd, x397[(size_t)i * nItems + item]);
             Mt rnd = tab.r;
             float ox, oy;
             if (F.jitter) { ox = rng_float(rnd); oy = rng_float(rnd); }
@@ -161,10 +198,14 @@ FD void path_store(const PathQueue& Q, uint32_t i, const PathState& s)
     Q.rndJ[i] = s.rnd.j; Q.rndA[i] = s.rnd.a; Q.rndB[i] = s.rnd.b;
     Q.tabJ[i] = s.tab.j; Q.tabA[i] = s.tab.a; Q.tabB[i] = s.tab.b;
 }
-FD void path_load(const PathQueue& Q, uint32_t i, PathState& s)
+FD void path_load_ray(const PathQueue& Q, uint32_t i, PathState& s)
 {
     s.o = v3(Q.ox[i], Q.oy[i], Q.oz[i]);
     s.d = v3(Q.dx[i], Q.dy[i], Q.dz[i]);
+}
+// Everything but the ray: fetched after the closest-hit search so it is not live across it.
+FD void path_load_rest(const PathQueue& Q, uint32_t i, PathState& s)
+{
     s.pm = c3(Q.tr[i], Q.tg[i], Q.tb[i]);
     s.acc = c3(Q.ar[i], Q.ag[i], Q.ab[i]);
     s.slot = Q.slot[i];
@@ -175,20 +216,56 @@ FD void path_load(const PathQueue& Q, uint32_t i, PathState& s)
     s.tab.j = Q.tabJ[i]; s.tab.a = Q.tabA[i]; s.tab.b = Q.tabB[i];
 }
 
-// Appends the lanes with keep == true to queue Q: one atomicAdd per wave, lanes ranked by a
-// ballot prefix count.
-FD uint32_t wave_append(bool keep, uint32_t* counter)
+// ---- segmented path queues ---------------------------------------------------------------------------
+// A single global append counter is the bottleneck of a wavefront tracer on this chip: one word
+// sustains ~88 atomics/us, and a 1080p x 64spp frame needs ~8 M wave-level appends (measured: the
+// counter alone cost ~90 ms of a 190 ms frame).  So there is no global counter.  Every wave of the
+// producing kernel owns a contiguous range of input paths and writes its survivors, ranked by a
+// ballot prefix count, into its own contiguous segment of the output queue (capacity = its input
+// share, so it cannot overflow); it publishes one count.  A one-block scan turns the counts into
+// offsets, and a consumer lane maps its dense index to (segment, position) by a 13-step binary
+// search over the offsets held in LDS.
+#define FRAY_MAXSEG 8192   // = 2048 blocks x 4 waves, the largest grid grid_for() returns
+struct QMeta {
+    uint32_t n;        // live paths in the queue
+    uint32_t chunk;    // capacity (and stride) of one segment
+    uint32_t nSeg;
+    uint32_t pad;
+    uint32_t cnt[FRAY_MAXSEG];
+    uint32_t off[FRAY_MAXSEG + 1];
+};
+
+__global__ __launch_bounds__(1024) void k_scan(QMeta* m)
 {
-    unsigned long long mask = __ballot(keep);
-    uint32_t lane = __lane_id();
-    uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    uint32_t base = 0;
-    if (mask) {
-        int leader = __ffsll((long long)mask) - 1;
-        if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-        base = __shfl(base, leader);
+    __shared__ uint32_t part[1024];
+    const uint32_t nSeg = m->nSeg;
+    const uint32_t per = (nSeg + 1023u) / 1024u;
+    const uint32_t b = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < per; k++) if (b + k < nSeg) sum += m->cnt[b + k];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {      // Hillis-Steele inclusive scan
+        uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
     }
-    return base + rank;
+    uint32_t run = part[threadIdx.x] - sum;         // exclusive prefix of this thread's slice
+    for (uint32_t k = 0; k < per; k++)
+        if (b + k < nSeg) { m->off[b + k] = run; run += m->cnt[b + k]; }
+    if (threadIdx.x == 1023) { m->off[nSeg] = part[1023]; m->n = part[1023]; }
+}
+
+// Dense index -> storage index of a segmented queue (sOff = offsets in LDS).
+FD uint32_t seg_lookup(const uint32_t* sOff, uint32_t nSeg, uint32_t chunk, uint32_t i)
+{
+    uint32_t lo = 0, hi = nSeg;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (sOff[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo * chunk + (i - sOff[lo]);
 }
 
 FD void path_finish(float* __restrict__ sampleRad, DStats* st, const PathState& s, C3 add)
@@ -199,60 +276,73 @@ FD void path_finish(float* __restrict__ sampleRad, DStats* st, const PathState& 
     if (s.rnd.j > 227 || s.tab.j > 227) atomicAdd(&st->rngOverflow, 1ull);
 }
 
-// Batch = nItems pixels x `chunk` samples starting at sample s0; slot = s * nItems + item.
+// Batch = nItems pixels x `chunk` samples starting at sample s0; slot = s * nItems + item.  The first
+// queue is dense (entry = slot); slots of pixels outside the frame (ragged edge buckets) are marked dead.
+#define FRAY_DEAD 0xffffffffu
 template <bool ST>
 __global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFrame F, int nItems, int s0, int chunk, PathQueue Q,
-                                                 uint32_t* qcount, float* __restrict__ sampleRad, DStats* st)
+                                                 float* __restrict__ sampleRad, const uint32_t* __restrict__ x397, DStats* st)
 {
     Cnt c = zero_cnt();
     const uint32_t total = (uint32_t)nItems * (uint32_t)chunk;
-    const uint32_t span = (total + 63u) & ~63u;   // whole waves take part in the ballot
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < span; slot += gridDim.x * blockDim.x) {
-        bool live = false;
-        PathState ps;
-        if (slot < total) {
-            int item = (int)(slot % (uint32_t)nItems), s = (int)(slot / (uint32_t)nItems);
-            int x, y;
-            if (item_pixel(F, item, x, y)) {
-                const uint32_t p = (uint32_t)y * (uint32_t)F.W + (uint32_t)x;
-                ps.rnd = mt_seed(sample_seed(F.seed, p, (uint32_t)(s0 + s)));
-                ps.tab = ps.rnd;
-                float ox = rng_float(ps.rnd), oy = rng_float(ps.rnd);           // gi: always jittered (main.cpp:351-353)
-                double fx = (double)((float)x + ox), fy = (double)((float)y + oy);
-                if (C.dof) dof_ray(C, fx, fy, ps.tab, ps.o, ps.d); else screen_ray(C, fx, fy, ps.o, ps.d);
-                ps.pm = c3(1, 1, 1);
-                ps.acc = c3(0, 0, 0);
-                ps.slot = slot;
-                ps.depth = 0;
-                ps.flags = 0;
-                live = true;
-                bump<ST>(c.samples);
-            } else {
-                size_t q = (size_t)slot * 3;
-                sampleRad[q] = 0; sampleRad[q + 1] = 0; sampleRad[q + 2] = 0;
-            }
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += gridDim.x * blockDim.x) {
+        int item = (int)(slot % (uint32_t)nItems), s = (int)(slot / (uint32_t)nItems);
+        int x, y;
+        if (item_pixel(F, item, x, y)) {
+            PathState ps;
+            const uint32_t p = (uint32_t)y * (uint32_t)F.W + (uint32_t)x;
+            ps.rnd = mt_seed_with(sample_seed(F.seed, p, (uint32_t)(s0 + s)), x397[slot]);
+            ps.tab = ps.rnd;
+            float ox = rng_float(ps.rnd), oy = rng_float(ps.rnd);           // gi: always jittered (main.cpp:351-353)
+            double fx = (double)((float)x + ox), fy = (double)((float)y + oy);
+            if (C.dof) dof_ray(C, fx, fy, ps.tab, ps.o, ps.d); else screen_ray(C, fx, fy, ps.o, ps.d);
+            ps.pm = c3(1, 1, 1);
+            ps.acc = c3(0, 0, 0);
+            ps.slot = slot;
+            ps.depth = 0;
+            ps.flags = 0;
+            bump<ST>(c.samples);
+            path_store(Q, slot, ps);
+        } else {
+            Q.depthFlags[slot] = FRAY_DEAD;
+            size_t q = (size_t)slot * 3;
+            sampleRad[q] = 0; sampleRad[q + 1] = 0; sampleRad[q + 2] = 0;
         }
-        uint32_t dst = wave_append(live, qcount);
-        if (live) path_store(Q, dst, ps);
     }
     if (ST) flush_stats(st, c);
 }
 
 template <bool ST>
-__global__ __launch_bounds__(256) void k_pt_bounce(DScene S, PathQueue Qin, PathQueue Qout, const uint32_t* __restrict__ countIn,
-                                                   uint32_t* countOut, float* __restrict__ sampleRad, DStats* st)
+__global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, PathQueue Qin, PathQueue Qout, const QMeta* __restrict__ metaIn,
+                                                   QMeta* metaOut, float* __restrict__ sampleRad, DStats* st)
 {
+    __shared__ uint32_t sOff[FRAY_MAXSEG + 1];
     Cnt c = zero_cnt();
-    const uint32_t n = *countIn;
-    const uint32_t span = (n + 63u) & ~63u;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < span; i += gridDim.x * blockDim.x) {
+    const uint32_t n = metaIn->n, nSegIn = metaIn->nSeg, chunkIn = metaIn->chunk;
+    for (uint32_t k = threadIdx.x; k <= nSegIn; k += blockDim.x) sOff[k] = metaIn->off[k];
+    __syncthreads();
+    const uint32_t W = gridDim.x * (blockDim.x >> 6), w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t chunk = (((n + W - 1u) / W) + 63u) & ~63u;    // this launch's per-wave share = output segment size
+    const uint32_t begin = w * chunk;
+    const uint32_t end = begin + chunk < n ? begin + chunk : n;
+    uint32_t produced = 0;                                        // wave-uniform
+    for (uint32_t base = begin; base < end; base += 64u) {
+        const uint32_t di = base + lane;
         bool cont = false;
         PathState ps;
-        if (i < n) {
-            path_load(Qin, i, ps);
+        uint32_t i = 0;
+        bool live = di < end;
+        if (live) {
+            i = seg_lookup(sOff, nSegIn, chunkIn, di);
+            live = Qin.depthFlags[i] != FRAY_DEAD;
+        }
+        if (live) {
+            path_load_ray(Qin, i, ps);
             // entry test of pathtrace() (main.cpp:173-176) was applied before this path was queued
             HitRec h;
             closest_hit<ST>(S, ps.o, ps.d, h, c);
+            path_load_rest(Qin, i, ps);
             if (h.node <= -2) {                                       // main.cpp:201-208
                 C3 add = (ps.flags & RF_DIFFUSE) ? c3(0, 0, 0) : light_color(S.lights[-2 - h.node]) * ps.pm;
                 path_finish(sampleRad, st, ps, add);
@@ -285,9 +375,12 @@ __global__ __launch_bounds__(256) void k_pt_bounce(DScene S, PathQueue Qin, Path
                 }
             }
         }
-        uint32_t dst = wave_append(cont, countOut);
-        if (cont) path_store(Qout, dst, ps);
+        const unsigned long long mask = __ballot(cont);
+        if (cont) path_store(Qout, begin + produced + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), ps);
+        produced += (uint32_t)__popcll(mask);
     }
+    if (lane == 0) metaOut->cnt[w] = produced;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { metaOut->chunk = chunk; metaOut->nSeg = W; }
     if (ST) flush_stats(st, c);
 }
 

@@ -8,7 +8,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libfrayhip.so")
+# FRAYHIP_LIB: A/B-test another build of the same library (development only)
+_LIB_PATH = os.environ.get("FRAYHIP_LIB") or os.path.join(_HERE, "libfrayhip.so")
 
 
 class FrayError(RuntimeError):

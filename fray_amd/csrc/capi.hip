@@ -453,9 +453,12 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
         }
     } else if (f->mode == FRAYHIP_MODE_RENDER) {
         if (!d_rgb) { set_error("frayhip_render: MODE_RENDER needs an rgb buffer"); return FRAYHIP_E_ARG; }
-        if (sc->camera.stereoSeparation > 0) { set_error("frayhip_render: stereo cameras are not implemented on the device path yet"); return FRAYHIP_E_UNSUPPORTED; }
+        if (sc->camera.stereoSeparation > 0 && set.gi) {
+            // the right eye's path continues the left eye's random stream: inherently sequential
+            set_error("frayhip_render: stereo cameras are not implemented for path tracing on the device path yet");
+            return FRAYHIP_E_UNSUPPORTED;
+        }
         if (!set.gi) {
-            if (sc->whittedNeedsRecursion) { set_error("frayhip_render: Whitted recursion (Refl / Refr / Layered) is not implemented on the device path yet"); return FRAYHIP_E_UNSUPPORTED; }
             if (!F.jitter && spp > 5) { set_error("frayhip_render: bad sample count"); return FRAYHIP_E_ARG; }
             if (nItems > 0) {
                 // workspace: per-thread mt19937 state columns for samples that draw more than 227 words,
@@ -468,7 +471,10 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * spp + 3) / 4)), dim3(256), 0, stream, F, nItems, 0, spp, x397);
                 hipEvent_t a = pool_event(sc, 0), b = pool_event(sc, 1);
                 HIP_TRY(hipEventRecord(a, stream));
-                hipLaunchKernelGGL(k_whitted<ST>, dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats);
+                if (sc->whittedNeedsRecursion)
+                    hipLaunchKernelGGL((k_whitted<ST, true>), dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats);
+                else
+                    hipLaunchKernelGGL((k_whitted<ST, false>), dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats);
                 HIP_TRY(hipEventRecord(b, stream));
                 nTraceEvents = 2;
             }
@@ -522,7 +528,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     DStats ds;
     HIP_TRY(hipMemcpy(&ds, sc->d_stats, sizeof ds, hipMemcpyDeviceToHost));
     if (ds.rngOverflow) {
-        set_error("frayhip_render: a camera sample drew more than 227 random words; the register-resident mt19937 cannot follow the reference there");
+        set_error("frayhip_render: a camera sample left the supported envelope (path tracing: more than 227 random words per sample; Whitted: shade() nesting deeper than 40)");
         return FRAYHIP_E_UNSUPPORTED;
     }
     if (st) {

@@ -10,6 +10,7 @@
 //   k_pack/unpack  bucket-major <-> row-major copies for the multi-GPU gather
 #pragma once
 #include "dev_shade.hpp"
+#include "dev_whitted.hpp"
 
 #ifndef FRAY_BOUNCE_WAVES
 #define FRAY_BOUNCE_WAVES 3   // waves per SIMD the bounce kernel is register-allocated for (measured: 2 -> 215 ms, 3 -> 183 ms, 4 -> 183 ms)
@@ -36,17 +37,20 @@ FD void flush_stats(DStats* st, const Cnt& c)
 FD Cnt zero_cnt() { Cnt c; c.closest = c.shadow = c.node = c.kdInner = c.leafRefs = c.tri = c.prim = c.smooth = c.samples = c.tex = 0; return c; }
 
 // ---- camera (camera.cpp:59-92) ------------------------------------------------------------------
-FD void screen_ray(const DCamera& C, double x, double y, V3& o, V3& d)
+// which: 0 = CAMERA_CENTER, 1 = CAMERA_LEFT, 2 = CAMERA_RIGHT
+FD void screen_ray(const DCamera& C, double x, double y, V3& o, V3& d, int which = 0)
 {
     V3 tl = ld3(C.topLeft);
     d = tl + (ld3(C.topRight) - tl) * (x / C.w) + (ld3(C.bottomLeft) - tl) * (y / C.h);
     d = normalized(d);
     o = ld3(C.pos);
+    if (which == 1) o = o + ld3(C.rightDir) * -C.stereoSeparation;
+    else if (which == 2) o = o + ld3(C.rightDir) * C.stereoSeparation;
 }
 template <class G>
-FD void dof_ray(const DCamera& C, double x, double y, G& tab, V3& o, V3& d)
+FD void dof_ray(const DCamera& C, double x, double y, G& tab, V3& o, V3& d, int which = 0)
 {
-    screen_ray(C, x, y, o, d);
+    screen_ray(C, x, y, o, d, which);
     double M = C.focalPlaneDist / dot(ld3(C.frontDir), d);
     V3 T = ld3(C.pos) + d * M;
     double u, v;
@@ -128,7 +132,7 @@ FD C3 raytrace_flat(const DScene& S, V3 o, V3 d, G& tab, Cnt& c)
 
 __constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0, 0.6}, {0.6, 0.6}};   // main.cpp:55-61
 
-template <bool ST>
+template <bool ST, bool REC>
 __global__ __launch_bounds__(256) void k_whitted(DScene S, DCamera C, DFrame F, int nItems, float* __restrict__ rgb, uint32_t* mtWork,
                                                  const uint32_t* __restrict__ x397, DStats* st)
 {
@@ -150,10 +154,25 @@ __global__ __launch_bounds__(256) void k_whitted(DScene S, DCamera C, DFrame F, 
             if (F.jitter) { ox = rng_float(rnd); oy = rng_float(rnd); }
             else { ox = (float)kAAOffsets[i][0]; oy = (float)kAAOffsets[i][1]; }
             double fx = (double)((float)x + ox), fy = (double)((float)y + oy);   // int + float, main.cpp:359
-            V3 o, d;
-            if (C.dof) dof_ray(C, fx, fy, tab, o, d); else screen_ray(C, fx, fy, o, d);
-            bump<ST>(c.samples);
-            avg = avg + raytrace_flat<ST, MtLong>(S, o, d, tab, c);
+            if (C.stereoSeparation > 0) {                     // raytraceSinglePixel, main.cpp:306-317
+                V3 ol, dl, orr, dr;
+                if (C.dof) { dof_ray(C, fx, fy, tab, ol, dl, 1); dof_ray(C, fx, fy, tab, orr, dr, 2); }
+                else { screen_ray(C, fx, fy, ol, dl, 1); screen_ray(C, fx, fy, orr, dr, 2); }
+                bump<ST>(c.samples, 2);
+                C3 cl = REC ? raytrace_full<ST, MtLong>(S, ol, dl, tab, c, ovf) : raytrace_flat<ST, MtLong>(S, ol, dl, tab, c);
+                C3 cr = REC ? raytrace_full<ST, MtLong>(S, orr, dr, tab, c, ovf) : raytrace_flat<ST, MtLong>(S, orr, dr, tab, c);
+                if (S.saturation != 1) {                      // Color::adjustSaturation, color.h:127-133
+                    float ml = (cl.r + cl.g + cl.b) / 3.0f, mr = (cr.r + cr.g + cr.b) / 3.0f;
+                    cl = c3(ml + (cl.r - ml) * S.saturation, ml + (cl.g - ml) * S.saturation, ml + (cl.b - ml) * S.saturation);
+                    cr = c3(mr + (cr.r - mr) * S.saturation, mr + (cr.g - mr) * S.saturation, mr + (cr.b - mr) * S.saturation);
+                }
+                avg = avg + (cl * ldc(C.leftMask) + cr * ldc(C.rightMask));
+            } else {
+                V3 o, d;
+                if (C.dof) dof_ray(C, fx, fy, tab, o, d); else screen_ray(C, fx, fy, o, d);
+                bump<ST>(c.samples);
+                avg = avg + (REC ? raytrace_full<ST, MtLong>(S, o, d, tab, c, ovf) : raytrace_flat<ST, MtLong>(S, o, d, tab, c));
+            }
             ovf = ovf || rnd.j > 227;
         }
         avg = avg / (float)F.spp;

@@ -64,7 +64,11 @@ WHITTED = [
     ("boxed.fray", 61, 47, dict(wantAA=1)),                                 # the 5-sample AA table (main.cpp:55-61)
     ("forest.fray", 160, 120, dict(wantAA=0, dof=1, numDOFSamples=8, interactive=0)),   # thin lens + Phong + checker + bump
     ("zaphod.fray", 129, 86, dict(wantAA=1, dof=1, numDOFSamples=12)),     # as shipped, fewer samples
-    ("hw12/sphtri.fray", 64, 48, dict(gi=0, wantAA=0)),
+    ("hw12/sphtri.fray", 64, 48, dict(gi=0, wantAA=0)),                    # 3 x 225 light samples: 1350 random words per hit
+    ("hw9/dragon.fray", 96, 64, dict(wantAA=0)),                            # glossy floor: 25 / 3 rejection-sampled reflections, recursion
+    ("smallpt.fray", 96, 72, dict(gi=0, wantAA=0)),                         # mirror + glass spheres under Whitted
+    ("smallpt.fray", 40, 30, dict(gi=0, wantAA=1, maxTraceDepth=2)),
+    ("forest.fray", 96, 72, dict(wantAA=0, interactive=0, stereoSeparation=0.25)),   # anaglyph: two eyes, saturation 0.1, colour masks
 ]
 
 
@@ -110,6 +114,106 @@ def test_path_traced_colour_vs_oracle(fray, abi, oracle, gpu, scene, W, H, over)
     # bits and a few of them take another branch: ray counts agree to 1e-4, not exactly
     for k in ("closest_rays", "shadow_rays", "node_tests"):
         assert abs(st[k] - ost[k]) <= 1e-4 * ost[k] + 2, k
+    s.close()
+
+
+LAYERED_SCENE = """
+GlobalSettings {
+	frameWidth 96
+	frameHeight 72
+	ambientLight (0.1, 0.1, 0.15)
+	maxTraceDepth 4
+	wantAA off
+}
+Camera camera {
+	position (0, 6, -14)
+	pitch -15
+	fov 60
+}
+RectLight l1 {
+	translate (0, 14, 0)
+	scale (6, 6, 6)
+	power 30
+	xSubd 2
+	ySubd 2
+}
+Plane floor {
+	limit 30
+}
+Sphere ball {
+	R 2
+}
+CheckerTexture checker {
+	color1 (0.9, 0.2, 0.1)
+	color2 (0.1, 0.2, 0.9)
+	scaling 2
+}
+Lambert diffuse {
+	texture checker
+}
+Phong shiny {
+	color (0.3, 0.6, 0.3)
+	specularExponent 40
+}
+Refl mirror {
+	multiplier 0.9
+}
+Refl rough {
+	glossiness 0.7
+	numSamples 5
+}
+Refr refraction {
+	ior 1.5
+	multiplier 0.95
+}
+Fresnel fresnel {
+	ior 1.5
+}
+Layered glass {
+	layer refraction (1, 1, 1)
+	layer mirror (1, 1, 1) fresnel
+}
+Layered lacquer {
+	layer diffuse (1, 1, 1)
+	layer shiny (0.3, 0.3, 0.3)
+	layer rough (0.1, 0.15, 0.2)
+}
+Layered nested {
+	layer lacquer (1, 1, 1)
+	layer glass (0.5, 0.5, 0.5)
+}
+Node floorNode {
+	geometry floor
+	shader lacquer
+}
+Node glassBall {
+	geometry ball
+	shader glass
+	translate (-3, 2, 0)
+}
+Node nestedBall {
+	geometry ball
+	shader nested
+	translate (3, 2, 1)
+	scale (1, 1.5, 1)
+	rotate (30, 10, 0)
+}
+"""
+
+
+def test_whitted_layered_glossy_refraction_recursion_vs_oracle(fray, abi, oracle, gpu, tmp_path):
+    f = tmp_path / "layered.fray"
+    f.write_text(LAYERED_SCENE)
+    s = fray.Scene.parseScene(str(f))
+    s.beginRender()
+    img, st = s.render(seed=42, stats=True)
+    ref, ost = oracle.render(s.desc, abi.MODE_RENDER, seed=42)
+    assert ref.mean() > 0.05 and np.all(np.isfinite(img))
+    assert np.all(rms(img, ref) <= RMS_TOL), rms(img, ref)
+    for k in ("samples",):
+        assert st[k] == ost[k]
+    for k in ("closest_rays", "shadow_rays", "node_tests"):        # libm ulps may flip a rejection-sampled draw
+        assert abs(st[k] - ost[k]) <= 1e-3 * ost[k] + 2, k
     s.close()
 
 
@@ -192,7 +296,7 @@ def test_unsupported_features_fail_loudly(fray, abi, gpu, tmp_path):
     with pytest.raises(fray.FrayError) as e:
         s.beginRender()
     assert e.value.code == abi.E_UNSUPPORTED
-    s2 = open_scene(fray, "hw9/dragon.fray", 64, 48)           # glossy Whitted recursion
+    s2 = open_scene(fray, "cornell_box.fray", 64, 48, stereoSeparation=1.0)   # stereo + gi: sequential random stream across eyes
     s2.beginRender()
     with pytest.raises(fray.FrayError) as e:
         s2.render()

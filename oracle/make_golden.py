@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ref_*.npz from oracle/_ref (the partial reference build; see
+oracle/ref_glue.cpp for exactly which code in it is reference object code and which is restated).
+
+    python oracle/make_golden.py            # needs /root/reference mounted (make ref)
+
+One subprocess per scene: the reference's `scene` is a process-wide singleton.  Each fixture holds
+  * probes: a strided set of camera rays plus seeded random rays -> id, dist, ip, norm, u, v
+    computed by the reference's own Node::intersect / Light::intersect object code;
+  * image: a small frame under the RNG contract (reference shaders, lights, camera; restated
+    integrator loop), float32.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+CASES = [
+    # name, scene, W, H, overrides, probe stride, n random rays
+    ("boxed_whitted", "boxed.fray", 64, 48, "wantAA=0", 3, 400),
+    ("boxed_aa", "boxed.fray", 32, 24, "wantAA=1", 5, 0),
+    ("zaphod_dof", "zaphod.fray", 48, 32, "wantAA=0;dof=1;numDOFSamples=6", 3, 200),
+    ("cornell_pt", "cornell_box.fray", 48, 48, "gi=1;numPaths=8", 3, 400),
+    ("smallpt_pt", "smallpt.fray", 48, 36, "gi=1;numPaths=8", 3, 400),
+    ("smallpt_whitted", "smallpt.fray", 48, 36, "gi=0;wantAA=0", 5, 0),
+    ("sphtri_pt", "hw12/sphtri.fray", 48, 36, "gi=1;numPaths=4", 5, 100),
+    ("dragon_whitted", "hw9/dragon.fray", 48, 32, "wantAA=0", 3, 300),
+]
+
+
+def worker(name, scene, W, H, over, stride, nrand):
+    lib = C.CDLL(os.path.join(HERE, "_ref", "libfray_ref.so"))
+    lib.ref_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p]
+    lib.ref_probe.argtypes = [C.c_void_p] * 3
+    lib.ref_camera_ray.argtypes = [C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    lib.ref_render.argtypes = [C.c_void_p, C.c_uint]
+    rc = lib.ref_load(os.path.join(ROOT, "scenes", scene).encode(), W, H, over.encode())
+    assert rc == 0, rc
+    rays = []
+    for y in range(0, H, stride):
+        for x in range(0, W, stride):
+            s, d = np.zeros(3), np.zeros(3)
+            lib.ref_camera_ray(float(x), float(y), s.ctypes.data, d.ctypes.data)
+            rays.append((s, d))
+    # secondary-like rays: start at primary hit points, go in seeded random directions
+    rng = np.random.default_rng(12345)
+    base = list(rays)
+    for k in range(nrand):
+        s, d = base[int(rng.integers(len(base)))]
+        out = np.zeros(9)
+        hid = lib.ref_probe(s.ctypes.data, d.ctypes.data, out.ctypes.data)
+        if hid < 0:
+            continue
+        v = rng.normal(size=3)
+        v /= np.linalg.norm(v)
+        if np.dot(v, out[4:7]) < 0:
+            v = -v
+        rays.append((out[1:4] + out[4:7] * 1e-6, v))
+    S = np.array([r[0] for r in rays])
+    D = np.array([r[1] for r in rays])
+    ids = np.zeros(len(rays), np.int32)
+    rec = np.zeros((len(rays), 9))
+    for i in range(len(rays)):
+        s, d = np.ascontiguousarray(S[i]), np.ascontiguousarray(D[i])
+        ids[i] = lib.ref_probe(s.ctypes.data, d.ctypes.data, rec[i].ctypes.data)
+    img = np.zeros((H, W, 3), np.float32)
+    lib.ref_render(img.ctypes.data, 42)
+    np.savez_compressed(os.path.join(OUT, "ref_%s.npz" % name), scene=scene, W=W, H=H, overrides=over, seed=42,
+                        ray_start=S, ray_dir=D, hit_id=ids, hit_rec=rec, image=img)
+    print(name, "rays", len(rays), "hits", int((ids != -1).sum()), "image mean %.4f" % img.mean(), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        a = sys.argv[1:]
+        worker(a[0], a[1], int(a[2]), int(a[3]), a[4], int(a[5]), int(a[6]))
+    else:
+        os.makedirs(OUT, exist_ok=True)
+        for c in CASES:
+            subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(x) for x in c], check=True)

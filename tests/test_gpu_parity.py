@@ -304,3 +304,20 @@ def test_unsupported_features_fail_loudly(fray, abi, gpu, tmp_path):
     s3 = open_scene(fray, "boxed.fray", 32, 32)
     with pytest.raises(fray.FrayError):
         s3.render()                                             # beginRender() not called
+
+
+import glob as _glob
+
+REF_FIXTURES = sorted(_glob.glob(os.path.join(ROOT, "tests", "golden", "ref_*.npz")))
+
+
+@pytest.mark.parametrize("path", REF_FIXTURES, ids=lambda p: os.path.basename(p)[4:-4])
+def test_gpu_colour_vs_reference_fixture(fray, gpu, path):
+    """HIP render vs the committed image produced by the partial reference build (reference object
+    code for shaders / lights / camera / geometry; tests/golden/ref_*.npz, oracle/make_golden.py)."""
+    from test_oracle_vs_ref import load_case
+    z, s = load_case(fray, path)
+    s.beginRender()
+    img, _ = s.render(seed=int(z["seed"]))
+    assert np.all(rms(img, z["image"]) <= RMS_TOL), rms(img, z["image"])
+    s.close()

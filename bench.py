@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--spp-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="N > 1: also render the whole frame on rank 0 and require the gathered frame to equal it")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the real multi-GPU run) or gloo (rehearsal: N ranks sharing GPU 0)")
     args = ap.parse_args()
 
     import torch
@@ -91,13 +93,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if args.backend == "gloo":
+        local_rank = 0                      # rehearsal on a one-GPU box: every rank drives GPU 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     rc = fray_amd.lib.frayhip_init(local_rank)
     assert rc == 0, fray_amd.lib.frayhip_last_error()
 
@@ -112,7 +119,8 @@ def main():
     dists = torch.zeros((H, W), dtype=torch.float64, device=dev) if mode == abi.MODE_PRIMARY_ID else None
     lib = fray_amd.lib
     from fray_amd import tiles
-    gatherer = tiles.TileGather(W, H, 3, rank, world, dev, dist) if world > 1 else None
+    gatherer = tiles.TileGather(W, H, 3, rank, world, dev, dist, stage_host=(args.backend != "nccl")) if world > 1 else None
+    rdev = dev if args.backend == "nccl" else torch.device("cpu")     # where small reduction tensors live
 
     def stream_ptr():
         return torch.cuda.current_stream().cuda_stream
@@ -130,7 +138,7 @@ def main():
     # counters + algorithmic bytes of one frame (instrumented kernels, untimed)
     st_counts = step(stats=True)
     counts = torch.tensor([st_counts["closest_rays"], st_counts["shadow_rays"], st_counts["samples"], st_counts["alg_bytes_trace"]],
-                          dtype=torch.float64, device=dev)
+                          dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(counts)
     rays_total = float(counts[0] + counts[1])
@@ -153,11 +161,22 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t[0])
     ms_per_step = elapsed * 1e3 / args.steps
+
+    check = None
+    if args.check and world > 1 and mode == abi.MODE_RENDER:
+        step()
+        if rank == 0:
+            whole = torch.zeros_like(frame)
+            scene.render_device(whole.data_ptr(), seed=args.seed, bucket_first=0, bucket_stride=1, spp_chunk=args.spp_chunk,
+                                stream=stream_ptr(), mode=mode)
+            torch.cuda.synchronize()
+            check = bool(torch.equal(whole, frame))
+        dist.barrier()
 
     if rank == 0:
         # roofline of the dominant kernel on rank 0: algorithmic bytes (SURVEY 8d byte model, from the
@@ -189,6 +208,21 @@ def main():
                          "note": "algorithmic bytes per SURVEY 8(d); scene tables are L2/LDS resident, so this is not HBM traffic"},
             "kernel_ms_per_step": kernels_ms / args.steps,
         }
+        if check is not None:
+            out["gathered_frame_equals_single_rank_frame"] = check
+        # HBM traffic of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+        # separate runs of this same command; profiles/pmc_traffic_latest.json)
+        tr_path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+        if world == 1 and args.workload == "cornell_pt64" and os.path.exists(tr_path):
+            try:
+                tr = json.load(open(tr_path))["void k_pt_bounce<false>"]
+                f_kb = tr["FETCH_SIZE"]["total"] / tr["FETCH_SIZE"]["launches"]
+                w_kb = tr["WRITE_SIZE"]["total"] / tr["WRITE_SIZE"]["launches"]
+                out["roofline"]["traffic"] = (f_kb + w_kb) * 1024.0
+                out["roofline"]["traffic_note"] = ("rocprofv3 --pmc, per launch: FETCH_SIZE %.3g KB (raw; gfx950 may under-count wide reads by up to 2x) + "
+                                                   "WRITE_SIZE %.3g KB" % (f_kb, w_kb))
+            except (KeyError, ValueError, ZeroDivisionError):
+                pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(fray_amd, abi, wl, args.seed) if mode == abi.MODE_RENDER else None
         print(json.dumps(out), flush=True)

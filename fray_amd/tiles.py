@@ -31,9 +31,10 @@ class TileGather:
     """Buffers and the one exchange step.  pack(frame, W, H, rank, world, out) and
     unpack(packed, frame, W, H, rank, world) default to the HIP kernels."""
 
-    def __init__(self, W, H, channels, rank, world, device, dist, pack=device_pack, unpack=device_unpack, dst=0):
+    def __init__(self, W, H, channels, rank, world, device, dist, pack=device_pack, unpack=device_unpack, dst=0, stage_host=False):
         self.W, self.H, self.rank, self.world, self.dist, self.dst = W, H, rank, world, dist, dst
         self.pack, self.unpack = pack, unpack
+        self.stage_host = stage_host      # transport cannot move device memory (gloo rehearsal): bounce through the host
         n = bucket_count(W, H, 0, world) * BUCKET * BUCKET * channels        # rank 0 owns the most buckets
         self.packed = torch.zeros(n, dtype=torch.float32, device=device)
         self.recv = [torch.zeros_like(self.packed) for _ in range(world)] if rank == dst else None
@@ -43,7 +44,15 @@ class TileGather:
         if self.world == 1:
             return frame
         self.pack(frame, self.W, self.H, self.rank, self.world, self.packed)
-        self.dist.gather(self.packed, self.recv, dst=self.dst)
+        if self.stage_host:
+            host = self.packed.cpu()
+            got = [torch.zeros_like(host) for _ in range(self.world)] if self.rank == self.dst else None
+            self.dist.gather(host, got, dst=self.dst)
+            if self.rank == self.dst:
+                for r in range(self.world):
+                    self.recv[r].copy_(got[r])
+        else:
+            self.dist.gather(self.packed, self.recv, dst=self.dst)
         if self.rank == self.dst:
             for r in range(self.world):
                 if r != self.dst:

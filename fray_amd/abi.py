@@ -164,6 +164,7 @@ SYMBOLS = {
     "frayhip_pack_buckets_device": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "frayhip_unpack_buckets_device": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "frayhip_to_rgb32": (C.c_int, [VP, VP, C.c_int]),
+    "frayhip_save_bmp": (C.c_int, [C.c_char_p, VP, C.c_int, C.c_int]),
     "frayhip_debug_rng": (C.c_int, [u32, C.c_int, VP, VP, VP, C.c_int]),
     "frayhip_last_error": (C.c_char_p, []),
     "frayhip_abi_version": (C.c_int, []),

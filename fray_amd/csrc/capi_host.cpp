@@ -1,5 +1,6 @@
 // C ABI, host-only entry points (no HIP calls): scene parsing and small utilities.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <string>
 
@@ -57,6 +58,38 @@ int frayhip_to_rgb32(const float* rgb, uint32_t* out, int n_pixels)
         }
         out[i] = (c[2]) | (c[1] << 8) | (c[0] << 16);
     }
+    return FRAYHIP_OK;
+}
+
+int frayhip_save_bmp(const char* path, const float* rgb, int width, int height)
+{
+    if (!path || !rgb || width <= 0 || height <= 0) { frayhip_detail::set_error("frayhip_save_bmp: bad argument"); return FRAYHIP_E_ARG; }
+    FILE* fp = fopen(path, "wb");
+    if (!fp) { frayhip_detail::set_error(std::string("frayhip_save_bmp: cannot open ") + path); return FRAYHIP_E_ARG; }
+    int rowsz = width * 3;
+    if (rowsz % 4) rowsz += 4 - (rowsz % 4);
+    unsigned char hdr[54] = {0};
+    auto put32 = [&](int o, uint32_t v) { hdr[o] = v & 255; hdr[o + 1] = (v >> 8) & 255; hdr[o + 2] = (v >> 16) & 255; hdr[o + 3] = (v >> 24) & 255; };
+    hdr[0] = 'B'; hdr[1] = 'M';
+    put32(2, (uint32_t)(rowsz * height + 54));
+    put32(10, 54);
+    put32(14, 40);
+    put32(18, (uint32_t)width);
+    put32(22, (uint32_t)height);
+    hdr[26] = 1; hdr[28] = 24;
+    fwrite(hdr, 1, 54, fp);
+    std::string row((size_t)rowsz, '\0');
+    for (int y = height - 1; y >= 0; y--) {
+        for (int x = 0; x < width; x++) {
+            uint32_t t;
+            frayhip_to_rgb32(rgb + ((size_t)y * width + x) * 3, &t, 1);
+            row[(size_t)x * 3] = (char)(t & 0xff);
+            row[(size_t)x * 3 + 1] = (char)((t >> 8) & 0xff);
+            row[(size_t)x * 3 + 2] = (char)((t >> 16) & 0xff);
+        }
+        fwrite(row.data(), 1, (size_t)rowsz, fp);
+    }
+    fclose(fp);
     return FRAYHIP_OK;
 }
 

@@ -41,42 +41,49 @@ FD bool box_inside(const Box6& b, V3 v)   // BBox::inside, bbox.h:79-84
            b.loz - 1e-6 <= v.z && v.z <= b.hiz + 1e-6;
 }
 
-// One dimension of BBox::testIntersect (bbox.h:89-132): 0 = keep going, 1 = hit, 2 = reject.
-FD int box_dim(double sd, double dd, double rd, double lo, double hi, double su, double du, double lou, double hiu,
-               double sv, double dv, double lov, double hiv)
+// BBox::testIntersect (bbox.h:87-134), written as straight-line predicated code: on a 64-lane wave
+// every early `return` / `continue` of the reference is a divergent branch (exec-mask save /
+// restore + scalar branch) that costs more than the dozen FP64 operations it skips, and the wave
+// executes the union of its lanes' paths anyway.  Each face test below evaluates exactly the
+// expressions the reference evaluates (same operands, same order); only the control flow around
+// them is replaced by boolean algebra with the same truth table:
+//   rej  : the dimension's "moving away from the slab" test  -> the reference returns false
+//   skip : |dir| < 1e-9                                      -> `continue`
+//   near : dist to the vmin face not < 0 (else `continue`: the far face is skipped too)
+//   hitN / hitF : the face's hit point lies inside the other two extents (<= on both sides)
+struct BoxDim { bool rej, hit; };
+FD BoxDim box_dim(double sd, double dd, double rd, double lo, double hi, double su, double du, double lou, double hiu,
+                  double sv, double dv, double lov, double hiv)
 {
-    if ((dd < 0 && sd < lo) || (dd > 0 && sd > hi)) return 2;
-    if (fabs(dd) < 1e-9) return 0;
-    double dist = (lo - sd) * rd;
-    if (dist < 0) return 0;
-    double x = su + du * dist;
-    if (lou <= x && x <= hiu) {
-        double y = sv + dv * dist;
-        if (lov <= y && y <= hiv) return 1;
-    }
-    dist = (hi - sd) * rd;
-    if (dist < 0) return 0;
-    x = su + du * dist;
-    if (lou <= x && x <= hiu) {
-        double y = sv + dv * dist;
-        if (lov <= y && y <= hiv) return 1;
-    }
-    return 0;
+    BoxDim r;
+    r.rej = (dd < 0 && sd < lo) | (dd > 0 && sd > hi);
+    const bool skip = fabs(dd) < 1e-9;
+    const double d1 = (lo - sd) * rd;
+    const bool near = !(d1 < 0);
+    const double x1 = su + du * d1, y1 = sv + dv * d1;
+    const bool hitN = (lou <= x1) & (x1 <= hiu) & (lov <= y1) & (y1 <= hiv);
+    const double d2 = (hi - sd) * rd;
+    const bool far = !(d2 < 0);
+    const double x2 = su + du * d2, y2 = sv + dv * d2;
+    const bool hitF = far & (lou <= x2) & (x2 <= hiu) & (lov <= y2) & (y2 <= hiv);
+    r.hit = !r.rej & !skip & near & (hitN | hitF);
+    return r;
 }
 
-FD bool box_test(const Box6& b, V3 s, V3 d, V3 rd)   // BBox::testIntersect, bbox.h:87-134
+FD bool box_test(const Box6& b, V3 s, V3 d, V3 rd)
 {
-    if (box_inside(b, s)) return true;
-    int r;
-    // dim 0: u = 1 (y), v = 2 (z)
-    r = box_dim(s.x, d.x, rd.x, b.lox, b.hix, s.y, d.y, b.loy, b.hiy, s.z, d.z, b.loz, b.hiz);
-    if (r) return r == 1;
-    // dim 1: u = 0 (x), v = 2 (z)
-    r = box_dim(s.y, d.y, rd.y, b.loy, b.hiy, s.x, d.x, b.lox, b.hix, s.z, d.z, b.loz, b.hiz);
-    if (r) return r == 1;
-    // dim 2: u = 0 (x), v = 1 (y)
-    r = box_dim(s.z, d.z, rd.z, b.loz, b.hiz, s.x, d.x, b.lox, b.hix, s.y, d.y, b.loy, b.hiy);
-    return r == 1;
+    bool res = box_inside(b, s);
+    bool alive = !res;
+    // dim 0: u = 1 (y), v = 2 (z);  dim 1: u = 0 (x), v = 2 (z);  dim 2: u = 0 (x), v = 1 (y)
+    BoxDim a = box_dim(s.x, d.x, rd.x, b.lox, b.hix, s.y, d.y, b.loy, b.hiy, s.z, d.z, b.loz, b.hiz);
+    res |= alive & a.hit;
+    alive &= !a.rej & !a.hit;
+    a = box_dim(s.y, d.y, rd.y, b.loy, b.hiy, s.x, d.x, b.lox, b.hix, s.z, d.z, b.loz, b.hiz);
+    res |= alive & a.hit;
+    alive &= !a.rej & !a.hit;
+    a = box_dim(s.z, d.z, rd.z, b.loz, b.hiz, s.x, d.x, b.lox, b.hix, s.y, d.y, b.loy, b.hiy);
+    res |= alive & a.hit;
+    return res;
 }
 
 FD void box_set_hi(Box6& b, int axis, double v) { if (axis == 0) b.hix = v; else if (axis == 1) b.hiy = v; else b.hiz = v; }
@@ -92,24 +99,29 @@ FD bool tri_test(const FRAY_RO DTri* T, int culling, V3 s, V3 d, double& best, d
     // the whole 120-byte record is fetched up front: one memory round trip per triangle instead
     // of one per early-out stage (the walk is latency-bound, not bandwidth-bound)
     const V3 g = ld3(T->g), N = ld3(T->N), A = ld3(T->A), AC = ld3(T->AC), AB = ld3(T->AB);
-    if (culling && dot(d, g) > 0) return false;
+    // straight-line predicated form (see box_dim): every value is the reference's, the early
+    // returns are folded into `ok`
+    bool ok = !(culling && dot(d, g) > 0);
     V3 D = -d;
     double Dcr = dot(N, D);
-    if (fabs(Dcr) < 1e-12) return false;
+    ok &= !(fabs(Dcr) < 1e-12);
     double rDcr = 1 / Dcr;
     V3 H = s - A;
     double gamma = dot(N, H) * rDcr;
-    if (gamma < 0 || gamma > best) return false;
+    ok &= !(gamma < 0 || gamma > best);
+    if (!__any(ok)) return false;           // wave-uniform: nobody needs the barycentrics
     double l2 = dot(cross(H, AC), D) * rDcr;
-    if (l2 < 0 || l2 > 1) return false;
+    ok &= !(l2 < 0 || l2 > 1);
     double l3 = dot(cross(AB, H), D) * rDcr;
-    if (l3 < 0 || l3 > 1) return false;
+    ok &= !(l3 < 0 || l3 > 1);
     double l1 = 1 - (l2 + l3);
-    if (l1 < 0) return false;
-    best = gamma;
-    l2o = l2;
-    l3o = l3;
-    return true;
+    ok &= !(l1 < 0);
+    if (ok) {
+        best = gamma;
+        l2o = l2;
+        l3o = l3;
+    }
+    return ok;
 }
 
 // Mesh::intersect (mesh.cpp:144-165).  On true: gamma / tri / l2 / l3 describe info.

@@ -279,6 +279,10 @@ int  frayhip_unpack_buckets_device(const float* d_packed, float* d_frame, int wi
 /* vfb -> RGB32 with clamp, no gamma (displayVFB, sdl.cpp:63-74; Color::toRGB32, color.h:59-65). */
 int  frayhip_to_rgb32(const float* rgb, uint32_t* out, int n_pixels);
 
+/* Writes a float RGB frame as a 24-bit BMP the way Bitmap::saveBMP does (bitmap.cpp:197-236:
+ * clamp + round per toRGB32, bottom-up rows padded to 4 bytes). */
+int  frayhip_save_bmp(const char* path, const float* rgb, int width, int height);
+
 /* Test hook: runs the device restatement of the reference's random numbers (std::mt19937 +
  * libstdc++ distributions, random_generator.cpp:41-80) for one seed and returns, for i < n,
  * the i-th randfloat() of a fresh generator, the i-th randdouble() of a second and the i-th

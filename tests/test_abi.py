@@ -65,3 +65,19 @@ def test_product_does_not_reach_into_the_oracle():
             if fn.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
                 text = open(os.path.join(dp, fn), errors="replace").read()
                 assert "oracle" not in text.lower() or fn in ("dev_rng.hpp",), (fn, "mentions the oracle")
+
+
+def test_save_bmp_round_trips_through_the_loader(fray, tmp_path):
+    """frayhip_save_bmp (Bitmap::saveBMP) -> the scene loader's BMP reader (Bitmap::loadBMP)."""
+    import numpy as np
+    W, H = 7, 5                                         # row size not a multiple of 4
+    rgb = np.linspace(-0.1, 1.1, W * H * 3, dtype=np.float32).reshape(H, W, 3)
+    path = tmp_path / "t.bmp"
+    assert fray.lib.frayhip_save_bmp(str(path).encode(), rgb.ctypes.data, W, H) == 0
+    assert os.path.getsize(path) == 54 + ((W * 3 + 3) // 4 * 4) * H
+    (tmp_path / "s.fray").write_text('Camera camera {\n\tposition (0,0,0)\n}\nBitmapTexture t {\n\tfile "t.bmp"\n}\n')
+    s = fray.Scene.parseScene(str(tmp_path / "s.fray"))
+    t = s.desc.textures[0]
+    tex = np.ctypeslib.as_array(s.desc.texels, shape=(s.desc.n_texels,))[t.texel_offset:t.texel_offset + W * H * 3].reshape(H, W, 3)
+    want = np.floor(np.clip(rgb, 0, 1) * np.float32(255) + np.float32(0.5)) / np.float32(255)
+    assert np.array_equal(tex, want.astype(np.float32))

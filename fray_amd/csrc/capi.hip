@@ -54,6 +54,7 @@ struct frayhip_scene {
     frayhip_camera camera{};
     frayhip_settings settings{};
     bool whittedNeedsRecursion = false;
+    bool extGeometry = false;         // Cube / CSG nodes present
     // per-frame workspace, grown on demand and kept between frames
     void* d_work = nullptr;
     size_t work_bytes = 0;
@@ -157,14 +158,16 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     if (desc->abi_version != FRAYHIP_ABI_VERSION) { set_error("frayhip_scene_create: ABI version mismatch"); return FRAYHIP_E_ARG; }
     const frayhip_scene_desc& d = *desc;
     // ---- what the device path implements ----
-    for (int i = 0; i < d.n_nodes; i++) {
-        int k = d.geoms[d.nodes[i].geom].kind;
-        if (k == FRAYHIP_GEOM_CUBE || k == FRAYHIP_GEOM_CSG) {
-            set_error("frayhip_scene_create: Cube / CSG geometry is not implemented on the device path yet");
+    for (int i = 0; i < d.n_csgs; i++)
+        if (d.geoms[d.csgs[i].left].kind == FRAYHIP_GEOM_CSG || d.geoms[d.csgs[i].right].kind == FRAYHIP_GEOM_CSG) {
+            set_error("frayhip_scene_create: nested CSG operands are not implemented on the device path yet");
             return FRAYHIP_E_UNSUPPORTED;
         }
-    }
     frayhip_scene* sc = new frayhip_scene();
+    for (int i = 0; i < d.n_nodes; i++) {
+        int k = d.geoms[d.nodes[i].geom].kind;
+        if (k == FRAYHIP_GEOM_CUBE || k == FRAYHIP_GEOM_CSG) sc->extGeometry = true;   // selects the <ST | 2> kernel variants
+    }
     Arena A;
     // nodes
     std::vector<DNode> nodes(d.n_nodes);
@@ -192,6 +195,18 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     std::vector<DSphere> spheres(d.n_spheres);
     for (int i = 0; i < d.n_spheres; i++) { put3(spheres[i].O, d.spheres[i].O); spheres[i].R = d.spheres[i].R; }
     size_t oSpheres = A.add(spheres.data(), spheres.size() * sizeof(DSphere));
+    std::vector<DCube> cubes(d.n_cubes);
+    for (int i = 0; i < d.n_cubes; i++) { put3(cubes[i].O, d.cubes[i].O); cubes[i].halfSide = d.cubes[i].halfSide; }
+    size_t oCubes = A.add(cubes.data(), cubes.size() * sizeof(DCube));
+    std::vector<DCsg> csgs(d.n_csgs);
+    for (int i = 0; i < d.n_csgs; i++) {
+        const frayhip_csg& g = d.csgs[i];
+        csgs[i].op = g.op;
+        csgs[i].leftKind = d.geoms[g.left].kind; csgs[i].leftIndex = d.geoms[g.left].index; csgs[i].leftGeom = g.left;
+        csgs[i].rightKind = d.geoms[g.right].kind; csgs[i].rightIndex = d.geoms[g.right].index; csgs[i].rightGeom = g.right;
+        csgs[i].pad = 0;
+    }
+    size_t oCsgs = A.add(csgs.data(), csgs.size() * sizeof(DCsg));
     // meshes
     std::vector<DMesh> meshes(d.n_meshes);
     struct MeshOff { size_t tris, attrs, kd, refs; };
@@ -334,6 +349,8 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     S.nodes = (const FRAY_RO DNode*)(base + oNodes);
     S.planes = (const FRAY_RO DPlane*)(base + oPlanes);
     S.spheres = (const FRAY_RO DSphere*)(base + oSpheres);
+    S.cubes = (const FRAY_RO DCube*)(base + oCubes);
+    S.csgs = (const FRAY_RO DCsg*)(base + oCsgs);
     S.meshes = (const FRAY_RO DMesh*)(base + oMeshes);
     S.shaders = (const FRAY_RO DShader*)(base + oShaders);
     S.layers = (const FRAY_RO DLayer*)(base + oLayers);
@@ -411,7 +428,7 @@ hipEvent_t pool_event(frayhip_scene* sc, size_t i)
     return sc->evPool[i];
 }
 
-template <bool ST>
+template <int ST>
 int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t* d_id, double* d_dist, hipStream_t stream, frayhip_stats* st)
 {
     const auto t0 = std::chrono::steady_clock::now();
@@ -567,8 +584,9 @@ int frayhip_render_device(frayhip_scene* s, const frayhip_frame* f, float* d_rgb
 {
     if (!s || !f) { set_error("frayhip_render_device: null argument"); return FRAYHIP_E_ARG; }
     hipStream_t stream = (hipStream_t)hip_stream;
-    if (f->flags & FRAYHIP_FRAME_STATS) return render_impl<true>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st);
-    return render_impl<false>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st);
+    const bool stats = (f->flags & FRAYHIP_FRAME_STATS) != 0;
+    if (s->extGeometry) return stats ? render_impl<3>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st) : render_impl<2>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st);
+    return stats ? render_impl<1>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st) : render_impl<0>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st);
 }
 
 int frayhip_render(frayhip_scene* s, const frayhip_frame* f, float* rgb, int32_t* hit_id, double* hit_dist, frayhip_stats* st)

@@ -36,6 +36,8 @@ struct DNode {
 
 struct DPlane { double limit, height; };
 struct DSphere { double O[3]; double R; };
+struct DCube { double O[3]; double halfSide; };
+struct DCsg { int32_t op, leftKind, leftIndex, rightKind, rightIndex, leftGeom, rightGeom, pad; };   // kinds/indices as in DNode
 
 struct DTri {          // 128 B
     double g[3];       // gnormal
@@ -112,6 +114,8 @@ struct DScene {
     const FRAY_RO DNode* nodes;
     const FRAY_RO DPlane* planes;
     const FRAY_RO DSphere* spheres;
+    const FRAY_RO DCube* cubes;
+    const FRAY_RO DCsg* csgs;
     const FRAY_RO DMesh* meshes;
     const FRAY_RO DShader* shaders;
     const FRAY_RO DLayer* layers;
@@ -135,5 +139,5 @@ struct DFrame {
 
 // Device counters mirroring frayhip_stats (only maintained by the *_stats kernel variants).
 struct DStats {
-    unsigned long long closest, shadow, node, kdInner, leafRefs, tri, prim, smooth, samples, tex, rngOverflow;
+    unsigned long long closest, shadow, node, kdInner, leafRefs, tri, prim, smooth, samples, tex, rngOverflow;   // rngOverflow: any "left the supported envelope" event
 };

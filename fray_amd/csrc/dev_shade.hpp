@@ -18,6 +18,46 @@ struct HitInfo {           // IntersectionInfo, geometry.h:33-39 (after Node::in
 // Rebuilds what Node::intersect + <Geometry>::intersect leave in `info` for the winning node
 // (geometry.cpp:30-83, 196-208; mesh.cpp:112-137).  needUV gates the sphere's atan2/asin, whose
 // result only textures and bump maps read.
+// Local normal / uv of a non-CSG geometry at local point ipl (what its intersect() writes).
+FD void prim_attributes(const DScene& S, int kind, int index, V3 ipl, int code, double l2, double l3, bool needUV, V3& nl, HitInfo& info)
+{
+    if (kind == 0) {
+        nl = v3(0, 1, 0);
+        info.u = ipl.x;
+        info.v = ipl.z;
+    } else if (kind == 1) {
+        const FRAY_RO DSphere& Sp = S.spheres[index];
+        nl = normalized(ipl - ld3(Sp.O));
+        if (needUV) {
+            info.u = ((atan2(nl.z, nl.x) / FRAY_PI * 180.0) + 180.0) / 360.0;
+            info.v = 1 - ((asin(nl.y) / FRAY_PI * 180.0) + 90) / 180.0;
+        }
+    } else if (kind == 2) {   // Cube::intersect's per-side normal and uv lambdas, geometry.cpp:113-126
+        const int ax = code >> 1;
+        const double sg = (code & 1) ? +1.0 : -1.0;
+        nl = v3(ax == 0 ? sg : 0.0, ax == 1 ? sg : 0.0, ax == 2 ? sg : 0.0);
+        if (ax == 0) { info.u = ipl.y; info.v = ipl.z; }
+        else if (ax == 1) { info.u = ipl.x; info.v = ipl.z; }
+        else { info.u = ipl.x; info.v = ipl.y; }
+    } else {
+        const FRAY_RO DMesh& M = S.meshes[index];
+        const FRAY_RO DTriAttr* A = M.attrs + code;
+        if (M.smooth) {
+            V3 nA = ld3(A->nA), nB = ld3(A->nB), nC = ld3(A->nC);
+            nl = normalized(nA + (nB - nA) * l2 + (nC - nA) * l3);
+        } else {
+            nl = ld3(M.tris[code].g);
+        }
+        if (M.hasUV) {
+            info.u = A->tA[0] + (A->tB[0] - A->tA[0]) * l2 + (A->tC[0] - A->tA[0]) * l3;
+            info.v = A->tA[1] + (A->tB[1] - A->tA[1]) * l2 + (A->tC[1] - A->tA[1]) * l3;
+        }
+        info.dNdx = ld3(A->dNdx);
+        info.dNdy = ld3(A->dNdy);
+    }
+}
+
+template <int ST>
 FD void finalize_hit(const DScene& S, const HitRec& h, V3 o, V3 d, bool needUV, HitInfo& info)
 {
     const FRAY_RO DNode& N = S.nodes[h.node];
@@ -28,39 +68,30 @@ FD void finalize_hit(const DScene& S, const HitRec& h, V3 o, V3 d, bool needUV, 
     info.dNdx = v3(0, 0, 0);
     info.dNdy = v3(0, 0, 0);
     info.u = 0; info.v = 0;
-    if (N.geomKind == 0) {
-        nl = v3(0, 1, 0);
-        info.u = ipl.x;
-        info.v = ipl.z;
-    } else if (N.geomKind == 1) {
-        const FRAY_RO DSphere& Sp = S.spheres[N.geomIndex];
-        nl = normalized(ipl - ld3(Sp.O));
-        if (needUV) {
-            info.u = ((atan2(nl.z, nl.x) / FRAY_PI * 180.0) + 180.0) / 360.0;
-            info.v = 1 - ((asin(nl.y) / FRAY_PI * 180.0) + 90) / 180.0;
-        }
+    if ((ST & 2) && N.geomKind == 2) {
+        GHit g;
+        cube_intersect(S.cubes[N.geomIndex], ls, ldir, g);       // same arithmetic as during the search
+        ipl = g.ip;
+        prim_attributes(S, 2, N.geomIndex, ipl, g.code, 0, 0, needUV, nl, info);
+    } else if ((ST & 2) && N.geomKind == 4) {
+        const FRAY_RO DCsg& G = S.csgs[N.geomIndex];
+        GHit g;
+        int which = 0;
+        bool env = false;
+        Cnt dummy;
+        dummy.envelope = 0;
+        csg_intersect<(ST & 2)>(S, G, ls, ldir, g, which, env, dummy);
+        ipl = g.ip;
+        prim_attributes(S, which == 0 ? G.leftKind : G.rightKind, which == 0 ? G.leftIndex : G.rightIndex, ipl, g.code, g.l2, g.l3, needUV, nl, info);
     } else {
-        const FRAY_RO DMesh& M = S.meshes[N.geomIndex];
-        const FRAY_RO DTriAttr* A = M.attrs + h.tri;
-        if (M.smooth) {
-            V3 nA = ld3(A->nA), nB = ld3(A->nB), nC = ld3(A->nC);
-            nl = normalized(nA + (nB - nA) * h.l2 + (nC - nA) * h.l3);
-        } else {
-            nl = ld3(M.tris[h.tri].g);
-        }
-        if (M.hasUV) {
-            info.u = A->tA[0] + (A->tB[0] - A->tA[0]) * h.l2 + (A->tC[0] - A->tA[0]) * h.l3;
-            info.v = A->tA[1] + (A->tB[1] - A->tA[1]) * h.l2 + (A->tC[1] - A->tA[1]) * h.l3;
-        }
-        info.dNdx = ld3(A->dNdx);
-        info.dNdy = ld3(A->dNdy);
+        prim_attributes(S, N.geomKind, N.geomIndex, ipl, h.tri, h.l2, h.l3, needUV, nl, info);
     }
     info.ip = mulM(ipl, N.T.m) + ld3(N.T.off);
     info.norm = normalized(mulM(nl, N.T.m));
 }
 
 // ---- textures -----------------------------------------------------------------------------------
-template <bool ST>
+template <int ST>
 FD C3 texel(const FRAY_RO DTexture& T, int x, int y, Cnt& c)   // Bitmap::getPixel, bitmap.cpp:67-71
 {
     bump<ST>(c.tex);
@@ -83,7 +114,7 @@ FD float fresnel_schlick(V3 i, V3 n, float ior)   // shading.cpp:230-236
     float NdotI = (float)-dot(n, i);
     return f + (1.0f - f) * powf(1.0f - NdotI, 5.0f);
 }
-template <bool ST>
+template <int ST>
 FD C3 texture_sample(const DScene& S, int t, V3 rayDir, const HitInfo& info, Cnt& c)
 {
     const FRAY_RO DTexture& T = S.textures[t];
@@ -108,7 +139,7 @@ FD C3 texture_sample(const DScene& S, int t, V3 rayDir, const HitInfo& info, Cnt
     return c3(0, 0, 0);   // BumpTexture::sample, shading.cpp:392-395
 }
 // applyBumpMapping (main.cpp:82-90) -> BumpTexture::modifyNormal (shading.cpp:397-418)
-template <bool ST>
+template <int ST>
 FD void apply_bump(const DScene& S, int nodeIdx, HitInfo& info, Cnt& c)
 {
     int bt = S.nodes[nodeIdx].bumpTex;
@@ -125,7 +156,7 @@ FD void apply_bump(const DScene& S, int nodeIdx, HitInfo& info, Cnt& c)
 }
 
 // CubemapEnvironment::getEnvironment, environment.cpp:64-98
-template <bool ST>
+template <int ST>
 FD C3 environment(const DScene& S, V3 dir, Cnt& c)
 {
     if (!S.env.present || !S.env.loaded) return c3(0, 0, 0);
@@ -190,7 +221,7 @@ FD double light_solid_angle(const FRAY_RO DLight& L, V3 ip)
 }
 
 // ---- Whitted: Lambert::shade / Phong::shade (shading.cpp:48-80, 101-144) ---------------------------
-template <bool ST, class G>
+template <int ST, class G>
 FD C3 shade_direct(const DScene& S, const FRAY_RO DShader& sh, V3 rayDir, const HitInfo& info, G& tab, bool phong, Cnt& c)
 {
     C3 diffuse = ldc(sh.color);
@@ -305,7 +336,7 @@ FD void spawn_ray(const FRAY_RO DShader& sh, const HitInfo& x, const PathRay& w_
 
 // explicitLightSample, main.cpp:118-169.  `rnd` is the worker's local generator, `tab` the
 // per-thread table generator (RectLight::getNthSample draws from the latter).
-template <bool ST>
+template <int ST>
 FD C3 explicit_light_sample(const DScene& S, V3 rayDir, const HitInfo& info, C3 pm, const FRAY_RO DShader& sh, Mt& rnd, Mt& tab, Cnt& c)
 {
     if (S.nLights == 0) return c3(0, 0, 0);

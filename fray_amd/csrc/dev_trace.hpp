@@ -15,8 +15,11 @@
 // Per-lane work counters (frayhip_stats); only the <true> instantiations touch them.
 struct Cnt {
     unsigned long long closest, shadow, node, kdInner, leafRefs, tri, prim, smooth, samples, tex;
+    unsigned envelope;   // always maintained: a CSG operand produced more hits than FRAY_CSG_MAX
 };
-template <bool ST> FD void bump(unsigned long long& c, unsigned long long n = 1) { if (ST) c += n; }
+// Template flag word of the trace / shade code: bit 0 = maintain the work counters, bit 1 = the scene
+// has Cube / CSG geometry (kept out of the common kernels: its hit lists live in scratch memory).
+template <int ST> FD void bump(unsigned long long& c, unsigned long long n = 1) { if (ST & 1) c += n; }
 
 // Closest-hit record.  Shading attributes (ip, normal, uv, dNdx/dNdy) are re-derived from it for
 // the winning node only (finalize_hit in dev_shade.hpp) -- same arithmetic, so same bits.
@@ -92,7 +95,7 @@ FD void box_set_lo(Box6& b, int axis, double v) { if (axis == 0) b.lox = v; else
 // Mesh::intersectTriangle + Triangle::intersectFast (mesh.cpp:102-141, triangle.cpp:66-94),
 // test part only.  `best` is info.dist: accepted when gamma <= best, so the LAST equal-distance
 // triangle in visiting order wins, as in the reference.
-template <bool ST>
+template <int ST>
 FD bool tri_test(const FRAY_RO DTri* T, int culling, V3 s, V3 d, double& best, double& l2o, double& l3o, Cnt& c)
 {
     bump<ST>(c.tri);
@@ -125,7 +128,7 @@ FD bool tri_test(const FRAY_RO DTri* T, int culling, V3 s, V3 d, double& best, d
 }
 
 // Mesh::intersect (mesh.cpp:144-165).  On true: gamma / tri / l2 / l3 describe info.
-template <bool ST>
+template <int ST>
 FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int& tri, double& l2, double& l3, Cnt& c)
 {
     const V3 s = lr.s, d = lr.d;
@@ -200,9 +203,131 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
     }
 }
 
+// ---- Cube and CSG (geometry.cpp:85-194) -- only in the <ST & 2> kernel variants ----------------------
+// One intersection as <Geometry>::intersect reports it, reduced to what later stages rebuild the
+// full IntersectionInfo from: dist (the geometry's own info.dist), the local hit point, and a code
+// (cube side / triangle index) with the triangle's barycentrics.
+struct GHit { double dist; V3 ip; int code; double l2, l3; };
+
+FD bool cube_intersect(const FRAY_RO DCube& Cb, V3 s, V3 d, GHit& h)   // Cube::intersect, geometry.cpp:85-137
+{
+    const V3 O = ld3(Cb.O);
+    const double hs = Cb.halfSide;
+    double best = 1e99;
+    for (int side = 0; side < 6; side++) {
+        const int ax = side >> 1;
+        const double st = comp(s, ax), dr = comp(d, ax);
+        const double target = (side & 1) ? comp(O, ax) + hs : comp(O, ax) - hs;
+        if (fabs(dr) < 1e-9) continue;
+        double mult = (target - st) / dr;
+        if (mult < 0) continue;
+        V3 ip = s + d * mult;
+        if (ip.x < O.x - hs - 1e-6 || ip.x > O.x + hs + 1e-6) continue;
+        if (ip.y < O.y - hs - 1e-6 || ip.y > O.y + hs + 1e-6) continue;
+        if (ip.z < O.z - hs - 1e-6 || ip.z > O.z + hs + 1e-6) continue;
+        double dist = length(s - ip);
+        if (dist < best) { best = dist; h.dist = dist; h.ip = ip; h.code = side; }
+    }
+    return best < 1e99;
+}
+
+// <Geometry>::intersect of a non-CSG geometry, by kind.
+template <int ST>
+FD bool prim_intersect(const DScene& S, int kind, int index, V3 s, V3 d, V3 rd, GHit& h, Cnt& c)
+{
+    h.code = -1; h.l2 = 0; h.l3 = 0;
+    if (kind == 0) {
+        bump<ST>(c.prim);
+        const FRAY_RO DPlane& P = S.planes[index];
+        if (s.y > P.height && d.y >= 0) return false;
+        if (s.y < P.height && d.y <= 0) return false;
+        double scaling = fabs(s.y - P.height) / fabs(d.y);
+        V3 ip = s + d * scaling;
+        if (fabs(ip.x) > P.limit) return false;
+        if (fabs(ip.z) > P.limit) return false;
+        h.ip = ip;
+        h.dist = length(s - ip);
+        return true;
+    }
+    if (kind == 1) {
+        bump<ST>(c.prim);
+        const FRAY_RO DSphere& Sp = S.spheres[index];
+        V3 H = s - ld3(Sp.O);
+        double B = 2 * dot(d, H);
+        double C = lengthSqr(H) - Sp.R * Sp.R;
+        double Disc = B * B - 4 * 1 * C;
+        if (Disc < 0) return false;
+        double sq = sqrt(Disc);
+        double p1 = (-B + sq) / (2 * 1.0), p2 = (-B - sq) / (2 * 1.0);
+        double smaller = p2 < p1 ? p2 : p1, larger = p1 < p2 ? p2 : p1;
+        if (larger < 0) return false;
+        double dd = (smaller >= 0) ? smaller : larger;
+        h.ip = s + d * dd;
+        h.dist = length(s - h.ip);
+        return true;
+    }
+    if (kind == 2) {
+        bump<ST>(c.prim);
+        return cube_intersect(S.cubes[index], s, d, h);
+    }
+    // mesh
+    LocalRay lr;
+    lr.s = s; lr.d = d; lr.rd = rd; lr.cls = 0; lr.haveRd = true;
+    double gamma;
+    int tri = -1;
+    double l2 = 0, l3 = 0;
+    if (!mesh_intersect<ST>(S.meshes[index], lr, gamma, tri, l2, l3, c)) return false;
+    h.dist = gamma; h.ip = s + d * gamma; h.code = tri; h.l2 = l2; h.l3 = l3;
+    return true;
+}
+
+#define FRAY_CSG_MAX 16   // intersections kept per operand (the reference keeps up to 30)
+
+// CsgOp::intersect (geometry.cpp:139-194).  `which` of the winner: 0 = left operand, 1 = right.
+// Hits are ordered with a stable insertion sort, which is what libstdc++'s std::sort does for up
+// to 16 elements; beyond that equal-distance ties could be ordered differently, and more than
+// FRAY_CSG_MAX hits on one operand are reported through `envelope`.
+template <int ST>
+FD bool csg_intersect(const DScene& S, const FRAY_RO DCsg& G, V3 s, V3 d, GHit& win, int& which, bool& envelope, Cnt& c)
+{
+    GHit hits[2 * FRAY_CSG_MAX];
+    unsigned char side[2 * FRAY_CSG_MAX];
+    int n = 0, cnt[2] = {0, 0};
+    V3 rd;
+    rd.x = fabs(d.x) > 1e-12 ? 1.0 / d.x : 1e12;
+    rd.y = fabs(d.y) > 1e-12 ? 1.0 / d.y : 1e12;
+    rd.z = fabs(d.z) > 1e-12 ? 1.0 / d.z : 1e12;
+    for (int op = 0; op < 2; op++) {   // findAllIntersections, geometry.cpp:139-159
+        const int kind = op == 0 ? G.leftKind : G.rightKind, index = op == 0 ? G.leftIndex : G.rightIndex;
+        V3 start = s;
+        GHit h;
+        while (prim_intersect<ST>(S, kind, index, start, d, rd, h, c)) {
+            if (cnt[op] == FRAY_CSG_MAX) { envelope = true; break; }
+            if (cnt[op] > 0) h.dist = length(h.ip - s);
+            hits[n] = h; side[n] = (unsigned char)op; n++; cnt[op]++;
+            start = h.ip + d * 1e-6;
+        }
+    }
+    for (int i = 1; i < n; i++) {      // stable insertion sort by dist
+        GHit h = hits[i];
+        unsigned char sd = side[i];
+        int j = i;
+        while (j > 0 && h.dist < hits[j - 1].dist) { hits[j] = hits[j - 1]; side[j] = side[j - 1]; j--; }
+        hits[j] = h; side[j] = sd;
+    }
+    bool inL = (cnt[0] & 1) == 1, inR = (cnt[1] & 1) == 1;
+    auto bop = [&](bool l, bool r) { return G.op == 0 ? (l || r) : (G.op == 1 ? (l && r) : (l && !r)); };
+    const bool cur = bop(inL, inR);
+    for (int i = 0; i < n; i++) {
+        if (side[i] == 0) inL = !inL; else inR = !inR;
+        if (bop(inL, inR) != cur) { win = hits[i]; which = side[i]; return true; }
+    }
+    return false;
+}
+
 // Geometry part of Node::intersect for node N on the local ray; on a hit returns the local
 // intersection point and fills t / tri / l2 / l3.
-template <bool ST>
+template <int ST>
 FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, LocalRay& lr, V3& ipl, double& t, int& tri, double& l2, double& l3, Cnt& c)
 {
     const V3 ls = lr.s, ld = lr.d;
@@ -241,6 +366,27 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, LocalRay& lr, V3
         t = dd;
         return true;
     }
+    if ((ST & 2) && N.geomKind == 2) {   // Cube
+        bump<ST>(c.prim);
+        GHit h;
+        if (!cube_intersect(S.cubes[N.geomIndex], ls, ld, h)) return false;
+        ipl = h.ip;
+        tri = h.code;
+        t = h.dist;
+        return true;
+    }
+    if ((ST & 2) && N.geomKind == 4) {   // CSG: the winner is re-derived in finalize_hit
+        GHit h;
+        int which = 0;
+        bool env = false;
+        if (!csg_intersect<ST>(S, S.csgs[N.geomIndex], ls, ld, h, which, env, c)) return false;
+        if (env) c.envelope = 1;
+        ipl = h.ip;
+        tri = h.code;
+        t = h.dist;
+        l2 = h.l2; l3 = h.l3;
+        return true;
+    }
     // mesh
     const FRAY_RO DMesh& M = S.meshes[N.geomIndex];
     double gamma;
@@ -250,9 +396,8 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, LocalRay& lr, V3
     return true;
 }
 
-
 // Node::intersect (geometry.cpp:196-208) reduced to what the closest-hit comparison needs.
-template <bool ST>
+template <int ST>
 FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double& dist, double& t, int& tri, double& l2, double& l3, Cnt& c)
 {
     bump<ST>(c.node);
@@ -271,7 +416,7 @@ FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double&
 }
 
 // RectLight::intersect (lights.cpp:79-103); point lights are never hit (lights.h:68-71).
-template <bool ST>
+template <int ST>
 FD bool light_intersect(const FRAY_RO DLight& L, V3 o, V3 d, double& dist, Cnt& c)
 {
     if (L.kind == 0) return false;
@@ -291,7 +436,7 @@ FD bool light_intersect(const FRAY_RO DLight& L, V3 o, V3 d, double& dist, Cnt& 
 }
 
 // The two loops of raytrace()/pathtrace(): first node wins ties (strict <), then lights.
-template <bool ST>
+template <int ST>
 FD void closest_hit(const DScene& S, V3 o, V3 d, HitRec& best, Cnt& c)
 {
     bump<ST>(c.closest);
@@ -310,7 +455,7 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitRec& best, Cnt& c)
             best.node = i; best.tri = tri; best.dist = dist; best.t = t; best.l2 = l2; best.l3 = l3;
         }
     }
-    if (ST && best.node >= 0) {   // byte model: the winner's corner normals / uvs
+    if ((ST & 1) && best.node >= 0) {   // byte model: the winner's corner normals / uvs
         const FRAY_RO DNode& W = S.nodes[best.node];
         if (W.geomKind == 3 && S.meshes[W.geomIndex].smooth) c.smooth++;
     }
@@ -326,7 +471,7 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitRec& best, Cnt& c)
 
 // visible(a, b), main.cpp:64-80: lights do not occlude; the first node whose (full) intersection
 // lies closer than b ends the loop.
-template <bool ST>
+template <int ST>
 FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c)
 {
     bump<ST>(c.shadow);

@@ -20,7 +20,7 @@ struct WFrame {
 
 #define FRAY_WSTACK 40
 
-template <bool ST, class G>
+template <int ST, class G>
 FD C3 raytrace_full(const DScene& S, V3 o0, V3 d0, G& tab, Cnt& c, bool& overflow)
 {
     WFrame stack[FRAY_WSTACK];
@@ -41,7 +41,7 @@ FD C3 raytrace_full(const DScene& S, V3 o0, V3 d0, G& tab, Cnt& c, bool& overflo
             if (h.node < 0) { ret = environment<ST>(S, d, c); mode = RET; continue; }
             const FRAY_RO DNode& N = S.nodes[h.node];
             shader = N.shader;
-            finalize_hit(S, h, o, d, S.shaders[shader].usesUV || N.bumpTex >= 0, info);
+            finalize_hit<ST>(S, h, o, d, S.shaders[shader].usesUV || N.bumpTex >= 0, info);
             apply_bump<ST>(S, h.node, info, c);
             mode = SHADE;
             continue;

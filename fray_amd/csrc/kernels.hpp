@@ -34,7 +34,7 @@ FD void flush_stats(DStats* st, const Cnt& c)
     atomicAdd(&st->prim, c.prim); atomicAdd(&st->smooth, c.smooth); atomicAdd(&st->samples, c.samples);
     atomicAdd(&st->tex, c.tex);
 }
-FD Cnt zero_cnt() { Cnt c; c.closest = c.shadow = c.node = c.kdInner = c.leafRefs = c.tri = c.prim = c.smooth = c.samples = c.tex = 0; return c; }
+FD Cnt zero_cnt() { Cnt c; c.closest = c.shadow = c.node = c.kdInner = c.leafRefs = c.tri = c.prim = c.smooth = c.samples = c.tex = 0; c.envelope = 0; return c; }
 
 // ---- camera (camera.cpp:59-92) ------------------------------------------------------------------
 // which: 0 = CAMERA_CENTER, 1 = CAMERA_LEFT, 2 = CAMERA_RIGHT
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_seed(DFrame F, int nItems, int s0, int 
 }
 
 // ---- MODE_PRIMARY_ID ------------------------------------------------------------------------------
-template <bool ST>
+template <int ST>
 __global__ __launch_bounds__(256) void k_primary(DScene S, DCamera C, DFrame F, int nItems, int32_t* __restrict__ hitId,
                                                  double* __restrict__ hitDist, DStats* st)
 {
@@ -110,11 +110,12 @@ __global__ __launch_bounds__(256) void k_primary(DScene S, DCamera C, DFrame F, 
         if (hitId) hitId[p] = h.node;
         if (hitDist) hitDist[p] = h.dist;
     }
-    if (ST) flush_stats(st, c);
+    if (ST & 1) flush_stats(st, c);
+    if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
 
 // ---- Whitted (main.cpp:246-285), shaders without recursion --------------------------------------
-template <bool ST, class G>
+template <int ST, class G>
 FD C3 raytrace_flat(const DScene& S, V3 o, V3 d, G& tab, Cnt& c)
 {
     HitRec h;
@@ -124,7 +125,7 @@ FD C3 raytrace_flat(const DScene& S, V3 o, V3 d, G& tab, Cnt& c)
     const FRAY_RO DNode& N = S.nodes[h.node];
     const FRAY_RO DShader& sh = S.shaders[N.shader];
     HitInfo info;
-    finalize_hit(S, h, o, d, sh.usesUV || N.bumpTex >= 0, info);
+    finalize_hit<ST>(S, h, o, d, sh.usesUV || N.bumpTex >= 0, info);
     apply_bump<ST>(S, h.node, info, c);
     if (sh.kind == 0) return ldc(sh.color);                          // ConstantShader::shade
     return shade_direct<ST, G>(S, sh, d, info, tab, sh.kind == 2, c);   // Lambert / Phong
@@ -132,7 +133,7 @@ FD C3 raytrace_flat(const DScene& S, V3 o, V3 d, G& tab, Cnt& c)
 
 __constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0, 0.6}, {0.6, 0.6}};   // main.cpp:55-61
 
-template <bool ST, bool REC>
+template <int ST, bool REC>
 __global__ __launch_bounds__(256) void k_whitted(DScene S, DCamera C, DFrame F, int nItems, float* __restrict__ rgb, uint32_t* mtWork,
                                                  const uint32_t* __restrict__ x397, DStats* st)
 {
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(256) void k_whitted(DScene S, DCamera C, DFrame F, 
         size_t q = (size_t)p * 3;
         rgb[q] = avg.r; rgb[q + 1] = avg.g; rgb[q + 2] = avg.b;
     }
-    if (ST) flush_stats(st, c);
+    if (ST & 1) flush_stats(st, c);
+    if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
 
 // ---- path tracer (main.cpp:171-244) as a wavefront ---------------------------------------------------
@@ -298,7 +300,7 @@ FD void path_finish(float* __restrict__ sampleRad, DStats* st, const PathState& 
 // Batch = nItems pixels x `chunk` samples starting at sample s0; slot = s * nItems + item.  The first
 // queue is dense (entry = slot); slots of pixels outside the frame (ragged edge buckets) are marked dead.
 #define FRAY_DEAD 0xffffffffu
-template <bool ST>
+template <int ST>
 __global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFrame F, int nItems, int s0, int chunk, PathQueue Q,
                                                  float* __restrict__ sampleRad, const uint32_t* __restrict__ x397, DStats* st)
 {
@@ -328,10 +330,11 @@ __global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFrame F, 
             sampleRad[q] = 0; sampleRad[q + 1] = 0; sampleRad[q + 2] = 0;
         }
     }
-    if (ST) flush_stats(st, c);
+    if (ST & 1) flush_stats(st, c);
+    if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
 
-template <bool ST>
+template <int ST>
 __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, PathQueue Qin, PathQueue Qout, const QMeta* __restrict__ metaIn,
                                                    QMeta* metaOut, float* __restrict__ sampleRad, DStats* st)
 {
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, 
                 const FRAY_RO DNode& N = S.nodes[h.node];
                 const FRAY_RO DShader& sh = S.shaders[N.shader];
                 HitInfo info;
-                finalize_hit(S, h, ps.o, ps.d, sh.usesUV || N.bumpTex >= 0, info);
+                finalize_hit<ST>(S, h, ps.o, ps.d, sh.usesUV || N.bumpTex >= 0, info);
                             apply_bump<ST>(S, h.node, info, c);
                 mt_skip(ps.tab, spawn_words(sh));                     // the discarded spawnRay (main.cpp:219-224)
                 C3 contribLight = explicit_light_sample<ST>(S, ps.d, info, ps.pm, sh, ps.rnd, ps.tab, c);
@@ -400,7 +403,8 @@ __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, 
     }
     if (lane == 0) metaOut->cnt[w] = produced;
     if (blockIdx.x == 0 && threadIdx.x == 0) { metaOut->chunk = chunk; metaOut->nSeg = W; }
-    if (ST) flush_stats(st, c);
+    if (ST & 1) flush_stats(st, c);
+    if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
 
 // vfb[y][x] = (sum over samples in order) / spp  (main.cpp:348-360).  `sum` carries the running

@@ -217,6 +217,137 @@ def test_whitted_layered_glossy_refraction_recursion_vs_oracle(fray, abi, oracle
     s.close()
 
 
+CSG_SCENE = """
+GlobalSettings {
+	frameWidth 120
+	frameHeight 90
+	ambientLight (0.2, 0.2, 0.25)
+	maxTraceDepth 4
+	wantAA off
+}
+Camera camera {
+	position (0, 9, -22)
+	pitch -18
+	fov 60
+}
+RectLight l1 {
+	translate (2, 20, -4)
+	scale (8, 8, 8)
+	power 60
+	xSubd 2
+	ySubd 2
+}
+Cube c0 {
+	halfSide 40
+}
+Cube c1 {
+	halfSide 40.001
+	O (0, -4, 0)
+}
+CsgMinus slab {
+	left c0
+	right c1
+}
+Cube box {
+	O (0, 0, 0)
+	halfSide 2
+}
+Sphere ball {
+	R 2.6
+}
+Sphere small {
+	O (1.2, 1.0, -1.0)
+	R 1.6
+}
+Mesh dice {
+	file "geom/truncated_cube.obj"
+	faceted true
+}
+CsgAnd rounded {
+	left box
+	right ball
+}
+CsgMinus bitten {
+	left ball
+	right small
+}
+CsgPlus fused {
+	left dice
+	right small
+}
+CheckerTexture checker {
+	color1 (0.8, 0.8, 0.2)
+	color2 (0.2, 0.2, 0.8)
+	scaling 3
+}
+Lambert tiles {
+	texture checker
+}
+Phong red {
+	color (0.9, 0.2, 0.2)
+	specularExponent 30
+}
+Lambert grey {
+	color (0.6, 0.6, 0.6)
+}
+Refl mirror {
+	multiplier 0.8
+}
+Node floorNode {
+	geometry slab
+	shader tiles
+	translate (0, -40, 0)
+}
+Node a {
+	geometry rounded
+	shader red
+	translate (-6, 2.5, 0)
+	rotate (30, 20, 0)
+}
+Node b {
+	geometry bitten
+	shader grey
+	translate (0, 3, 2)
+}
+Node c {
+	geometry fused
+	shader mirror
+	translate (6.5, 2.2, 0)
+	scale (0.5, 0.5, 0.5)
+	rotate (15, 0, 10)
+}
+Node plainCube {
+	geometry box
+	shader tiles
+	translate (0, 2, -7)
+	rotate (45, 0, 0)
+}
+"""
+
+
+@pytest.mark.parametrize("gi", [0, 1])
+def test_cube_and_csg_geometry_vs_oracle(fray, abi, oracle, gpu, tmp_path, gi):
+    import shutil
+    os.makedirs(tmp_path / "geom")
+    shutil.copy(os.path.join(ROOT, "scenes", "geom", "truncated_cube.obj"), tmp_path / "geom")
+    f = tmp_path / "csg.fray"
+    f.write_text(CSG_SCENE)
+    s = fray.Scene.parseScene(str(f))
+    s.settings.gi, s.settings.numPaths = gi, 6
+    s.beginRender()
+    ids, dist, st = s.primary_hits(stats=True)
+    oi, od, ost = oracle.render(s.desc, abi.MODE_PRIMARY_ID)
+    assert set(np.unique(oi)) >= {0, 1, 2, 3, 4}                    # every node is visible
+    assert np.array_equal(ids, oi) and np.array_equal(dist, od)     # bit-exact hit records through CSG
+    for k in COUNTERS:
+        assert st[k] == ost[k], k
+    img, _ = s.render(seed=42)
+    ref, _ = oracle.render(s.desc, abi.MODE_RENDER, seed=42)
+    assert ref.mean() > 0.02 and np.all(np.isfinite(img))
+    assert np.all(rms(img, ref) <= RMS_TOL), rms(img, ref)
+    s.close()
+
+
 def test_path_tracer_batching_and_seed_properties(fray, gpu):
     s = open_scene(fray, "cornell_box.fray", 80, 60, numPaths=7)
     s.beginRender()
@@ -290,11 +421,12 @@ def test_pack_unpack_buckets(fray, gpu):
 
 
 def test_unsupported_features_fail_loudly(fray, abi, gpu, tmp_path):
-    f = tmp_path / "cube.fray"
-    f.write_text("Camera camera {\n\tposition (0,0,-5)\n}\nCube c {\n}\nLambert l {\n}\nNode n {\n\tgeometry c\n\tshader l\n}\n")
+    f = tmp_path / "nested.fray"
+    f.write_text("Camera camera {\n\tposition (0,0,-5)\n}\nCube a {\n}\nSphere b {\n}\nCsgPlus ab {\n\tleft a\n\tright b\n}\n"
+                 "CsgMinus abc {\n\tleft ab\n\tright b\n}\nLambert l {\n}\nNode n {\n\tgeometry abc\n\tshader l\n}\n")
     s = fray.Scene.parseScene(str(f))
     with pytest.raises(fray.FrayError) as e:
-        s.beginRender()
+        s.beginRender()                                         # CSG of CSG
     assert e.value.code == abi.E_UNSUPPORTED
     s2 = open_scene(fray, "cornell_box.fray", 64, 48, stereoSeparation=1.0)   # stereo + gi: sequential random stream across eyes
     s2.beginRender()

@@ -89,8 +89,9 @@ FD bool box_test(const Box6& b, V3 s, V3 d, V3 rd)
     return res;
 }
 
-FD void box_set_hi(Box6& b, int axis, double v) { if (axis == 0) b.hix = v; else if (axis == 1) b.hiy = v; else b.hiz = v; }
-FD void box_set_lo(Box6& b, int axis, double v) { if (axis == 0) b.lox = v; else if (axis == 1) b.loy = v; else b.loz = v; }
+// pure selects: a store through a variable axis would push the whole box into scratch memory
+FD void box_set_hi(Box6& b, int axis, double v) { b.hix = axis == 0 ? v : b.hix; b.hiy = axis == 1 ? v : b.hiy; b.hiz = axis == 2 ? v : b.hiz; }
+FD void box_set_lo(Box6& b, int axis, double v) { b.lox = axis == 0 ? v : b.lox; b.loy = axis == 1 ? v : b.loy; b.loz = axis == 2 ? v : b.loz; }
 
 // Mesh::intersectTriangle + Triangle::intersectFast (mesh.cpp:102-141, triangle.cpp:66-94),
 // test part only.  `best` is info.dist: accepted when gamma <= best, so the LAST equal-distance

@@ -12,6 +12,12 @@
 #include "dev_shade.hpp"
 #include "dev_whitted.hpp"
 
+#ifndef FRAY_PRIMARY_WAVES
+#define FRAY_PRIMARY_WAVES 5
+#endif
+#ifndef FRAY_WHITTED_WAVES
+#define FRAY_WHITTED_WAVES 4   // measured on boxed / forest: 1 -> 47.8 / 112 ms, 2 -> 32.5 / 81, 3 -> 30.5 / 73, 4 -> 26.6 / 71.5
+#endif
 #ifndef FRAY_BOUNCE_WAVES
 #define FRAY_BOUNCE_WAVES 3   // waves per SIMD the bounce kernel is register-allocated for (measured: 2 -> 215 ms, 3 -> 183 ms, 4 -> 183 ms)
 #endif
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256) void k_seed(DFrame F, int nItems, int s0, int 
 
 // ---- MODE_PRIMARY_ID ------------------------------------------------------------------------------
 template <int ST>
-__global__ __launch_bounds__(256) void k_primary(DScene S, DCamera C, DFrame F, int nItems, int32_t* __restrict__ hitId,
+__global__ __launch_bounds__(256, FRAY_PRIMARY_WAVES) void k_primary(DScene S, DCamera C, DFrame F, int nItems, int32_t* __restrict__ hitId,
                                                  double* __restrict__ hitDist, DStats* st)
 {
     Cnt c = zero_cnt();
@@ -134,7 +140,7 @@ FD C3 raytrace_flat(const DScene& S, V3 o, V3 d, G& tab, Cnt& c)
 __constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0, 0.6}, {0.6, 0.6}};   // main.cpp:55-61
 
 template <int ST, bool REC>
-__global__ __launch_bounds__(256) void k_whitted(DScene S, DCamera C, DFrame F, int nItems, float* __restrict__ rgb, uint32_t* mtWork,
+__global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(DScene S, DCamera C, DFrame F, int nItems, float* __restrict__ rgb, uint32_t* mtWork,
                                                  const uint32_t* __restrict__ x397, DStats* st)
 {
     Cnt c = zero_cnt();

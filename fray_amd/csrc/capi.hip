@@ -59,7 +59,7 @@ struct frayhip_scene {
     void* d_work = nullptr;
     size_t work_bytes = 0;
     DStats* d_stats = nullptr;
-    QMeta* d_qmeta = nullptr;         // [2] segment tables of the ping-pong path queues
+    QMeta* d_qmeta = nullptr;         // [3] segment tables: ping-pong path queues + shadow queue
     hipEvent_t evA = nullptr, evB = nullptr;
     std::vector<hipEvent_t> evPool;
 };
@@ -368,7 +368,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     sc->camera = d.camera;
     sc->settings = d.settings;
     hipMalloc((void**)&sc->d_stats, sizeof(DStats));
-    hipMalloc((void**)&sc->d_qmeta, 2 * sizeof(QMeta));
+    hipMalloc((void**)&sc->d_qmeta, 3 * sizeof(QMeta));
     hipEventCreate(&sc->evA);
     hipEventCreate(&sc->evB);
     *out = sc;
@@ -410,7 +410,6 @@ unsigned char* carve_queue(unsigned char* p, size_t n, PathQueue& Q)
     Q.ox = (double*)take(n * 8); Q.oy = (double*)take(n * 8); Q.oz = (double*)take(n * 8);
     Q.dx = (double*)take(n * 8); Q.dy = (double*)take(n * 8); Q.dz = (double*)take(n * 8);
     Q.tr = (float*)take(n * 4); Q.tg = (float*)take(n * 4); Q.tb = (float*)take(n * 4);
-    Q.ar = (float*)take(n * 4); Q.ag = (float*)take(n * 4); Q.ab = (float*)take(n * 4);
     Q.slot = (uint32_t*)take(n * 4); Q.depthFlags = (uint32_t*)take(n * 4);
     Q.rndJ = (uint32_t*)take(n * 4); Q.rndA = (uint32_t*)take(n * 4); Q.rndB = (uint32_t*)take(n * 4);
     Q.tabJ = (uint32_t*)take(n * 4); Q.tabA = (uint32_t*)take(n * 4); Q.tabB = (uint32_t*)take(n * 4);
@@ -419,7 +418,21 @@ unsigned char* carve_queue(unsigned char* p, size_t n, PathQueue& Q)
 size_t queue_bytes(size_t n)
 {
     auto r = [](size_t b) { return (b + 255) / 256 * 256; };
-    return 6 * r(n * 8) + 14 * r(n * 4);
+    return 6 * r(n * 8) + 11 * r(n * 4);
+}
+unsigned char* carve_shadow(unsigned char* p, size_t n, ShadowQueue& Q)
+{
+    auto take = [&](size_t bytes) { unsigned char* r = p; p += (bytes + 255) / 256 * 256; return r; };
+    Q.ax = (double*)take(n * 8); Q.ay = (double*)take(n * 8); Q.az = (double*)take(n * 8);
+    Q.bx = (double*)take(n * 8); Q.by = (double*)take(n * 8); Q.bz = (double*)take(n * 8);
+    Q.cr = (float*)take(n * 4); Q.cg = (float*)take(n * 4); Q.cb = (float*)take(n * 4);
+    Q.slot = (uint32_t*)take(n * 4);
+    return p;
+}
+size_t shadow_bytes(size_t n)
+{
+    auto r = [](size_t b) { return (b + 255) / 256 * 256; };
+    return 6 * r(n * 8) + 4 * r(n * 4);
 }
 
 hipEvent_t pool_event(frayhip_scene* sc, size_t i)
@@ -501,13 +514,15 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             if (chunk > spp) chunk = spp;
             const size_t nPaths = (size_t)nItems * chunk;
             const size_t nQueue = nPaths + (size_t)FRAY_MAXSEG * 128;   // per-wave segments round their share up to 64
-            const size_t need = 2 * queue_bytes(nQueue) + nPaths * 12 + (size_t)nItems * 12 + nPaths * 4 + 8192;
+            const size_t need = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + (size_t)nItems * 12 + nPaths * 4 + 8192;
             int rc = ensure_work(sc, need);
             if (rc) return rc;
             PathQueue Q[2];
             unsigned char* p = (unsigned char*)sc->d_work;
             p = carve_queue(p, nQueue, Q[0]);
             p = carve_queue(p, nQueue, Q[1]);
+            ShadowQueue SQ;
+            p = carve_shadow(p, nQueue, SQ);
             float* sampleRad = (float*)p; p += (nPaths * 12 + 255) / 256 * 256;
             float* sum = (float*)p; p += ((size_t)nItems * 12 + 255) / 256 * 256;
             uint32_t* x397 = (uint32_t*)p;
@@ -526,11 +541,12 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 for (int b = 0; b < nBounce; b++) {
                     hipEvent_t ea = pool_event(sc, nTraceEvents), eb = pool_event(sc, nTraceEvents + 1);
                     HIP_TRY(hipEventRecord(ea, stream));
-                    hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, Q[b & 1], Q[(b + 1) & 1],
-                                       sc->d_qmeta + (b & 1), sc->d_qmeta + ((b + 1) & 1), sampleRad, sc->d_stats);
+                    hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, Q[b & 1], Q[(b + 1) & 1], SQ,
+                                       sc->d_qmeta + (b & 1), sc->d_qmeta + ((b + 1) & 1), sc->d_qmeta + 2, sampleRad, sc->d_stats);
+                    hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, stream, sc->d_qmeta + ((b + 1) & 1), sc->d_qmeta + 2);
+                    hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, SQ, sc->d_qmeta + 2, sampleRad, sc->d_stats);
                     HIP_TRY(hipEventRecord(eb, stream));
                     nTraceEvents += 2;
-                    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, sc->d_qmeta + ((b + 1) & 1));
                 }
                 hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, stream, F, nItems, s0, cn, sampleRad, sum, d_rgb);
             }

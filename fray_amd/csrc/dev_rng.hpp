@@ -110,8 +110,10 @@ FD void rng_unit_disc(G& r, double& x, double& y)
 {
     double angle = rng_double(r) * 2 * FRAY_PI;
     double rad = sqrt(rng_double(r));
-    x = sin(angle) * rad;
-    y = cos(angle) * rad;
+    double sa, ca;
+    sincos(angle, &sa, &ca);
+    x = sa * rad;
+    y = ca * rad;
 }
 
 // Generator without the 227-word limit, for the Whitted kernel (a Lambert hit under a 15x15

@@ -266,7 +266,10 @@ FD V3 hemisphere_sample(Mt& tab, V3 norm)   // main.cpp:92-116
     double v = rng_double(tab);
     double theta = 2 * FRAY_PI * u;
     double phi = acos(2 * v - 1);
-    V3 dir = v3(sin(phi) * cos(theta), cos(phi), sin(phi) * sin(theta));
+    double sp, cp, st, ct;          // one argument reduction per angle (the host compiler does the same to the reference)
+    sincos(phi, &sp, &cp);
+    sincos(theta, &st, &ct);
+    V3 dir = v3(sp * ct, cp, sp * st);
     if (dot(dir, norm) > 0) return dir;
     return -dir;
 }
@@ -334,7 +337,36 @@ FD void spawn_ray(const FRAY_RO DShader& sh, const HitInfo& x, const PathRay& w_
     pdf = 1;
 }
 
-// explicitLightSample, main.cpp:118-169.  `rnd` is the worker's local generator, `tab` the
+// explicitLightSample (main.cpp:118-169) with the visibility query split off: everything that draws
+// random numbers or evaluates the BRDF happens here; the returned segment a->b and the contribution
+// go to the shadow queue, and k_pt_shadow adds `contrib` iff visible(a, b).  The reference asks
+// visible() before eval(); neither draws random numbers, so the order does not matter.
+FD bool nee_prepare(const DScene& S, V3 rayDir, const HitInfo& info, C3 pm, const FRAY_RO DShader& sh, Mt& rnd, Mt& tab, V3& a, V3& b, C3& contrib)
+{
+    if (S.nLights == 0) return false;
+    int lightIdx = rng_int0(rnd, S.nLights - 1);
+    const FRAY_RO DLight& L = S.lights[lightIdx];
+    V3 x = info.ip;
+    double solidAngle = light_solid_angle(L, x);
+    if (solidAngle == 0) return false;
+    int randSample = rng_int0(rnd, light_num_samples(L) - 1);
+    V3 pointOnLight;
+    C3 unused;
+    light_nth_sample(L, randSample, x, tab, pointOnLight, unused);
+    a = x + info.norm * 1e-6;
+    b = pointOnLight;
+    C3 Le = light_color(L);
+    V3 w_out = normalized(pointOnLight - x);
+    C3 brdfAtPoint = brdf_eval(sh, info, w_out);
+    if (intensity(brdfAtPoint) == 0) { contrib = c3(0, 0, 0); return true; }
+    float probHitLightArea = (float)(1.0f / solidAngle);
+    float probPickThisLight = 1.0f / (float)S.nLights;
+    float chooseLightProb = probHitLightArea * probPickThisLight;
+    contrib = Le * pm * brdfAtPoint / chooseLightProb;
+    return true;
+}
+
+// explicitLightSample, main.cpp:118-169 (fused form, used by nothing on the hot path any more).  `rnd` is the worker's local generator, `tab` the
 // per-thread table generator (RectLight::getNthSample draws from the latter).
 template <int ST>
 FD C3 explicit_light_sample(const DScene& S, V3 rayDir, const HitInfo& info, C3 pm, const FRAY_RO DShader& sh, Mt& rnd, Mt& tab, Cnt& c)

@@ -18,6 +18,9 @@
 #ifndef FRAY_WHITTED_WAVES
 #define FRAY_WHITTED_WAVES 4   // measured on boxed / forest: 1 -> 47.8 / 112 ms, 2 -> 32.5 / 81, 3 -> 30.5 / 73, 4 -> 26.6 / 71.5
 #endif
+#ifndef FRAY_SHADOW_WAVES
+#define FRAY_SHADOW_WAVES 4
+#endif
 #ifndef FRAY_BOUNCE_WAVES
 #define FRAY_BOUNCE_WAVES 3   // waves per SIMD the bounce kernel is register-allocated for (measured: 2 -> 215 ms, 3 -> 183 ms, 4 -> 183 ms)
 #endif
@@ -193,21 +196,29 @@ __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(DScene S, D
 
 // ---- path tracer (main.cpp:171-244) as a wavefront ---------------------------------------------------
 // Path state, structure of arrays (one lane = one path, consecutive lanes = consecutive entries,
-// so every array is read and written fully coalesced).  92 bytes per path.
+// so every array is read and written fully coalesced).  80 bytes per path; radiance is accumulated in
+// the per-sample buffer (sampleRad[slot]), in bounce order, by k_pt_shadow and at termination.
 struct PathQueue {
     double* ox; double* oy; double* oz;
     double* dx; double* dy; double* dz;
     float* tr; float* tg; float* tb;      // pathMultiplier
-    float* ar; float* ag; float* ab;      // radiance gathered so far
     uint32_t* slot;                       // sample-major slot in the batch
     uint32_t* depthFlags;                 // depth | flags << 16
     uint32_t* rndJ; uint32_t* rndA; uint32_t* rndB;
     uint32_t* tabJ; uint32_t* tabA; uint32_t* tabB;
 };
 
+// Shadow (next-event) queue: segment a->b, the radiance to add if it is unobstructed, the sample slot.
+struct ShadowQueue {
+    double* ax; double* ay; double* az;
+    double* bx; double* by; double* bz;
+    float* cr; float* cg; float* cb;
+    uint32_t* slot;
+};
+
 struct PathState {
     V3 o, d;
-    C3 pm, acc;
+    C3 pm;
     uint32_t slot;
     int depth;
     unsigned flags;
@@ -219,7 +230,6 @@ FD void path_store(const PathQueue& Q, uint32_t i, const PathState& s)
     Q.ox[i] = s.o.x; Q.oy[i] = s.o.y; Q.oz[i] = s.o.z;
     Q.dx[i] = s.d.x; Q.dy[i] = s.d.y; Q.dz[i] = s.d.z;
     Q.tr[i] = s.pm.r; Q.tg[i] = s.pm.g; Q.tb[i] = s.pm.b;
-    Q.ar[i] = s.acc.r; Q.ag[i] = s.acc.g; Q.ab[i] = s.acc.b;
     Q.slot[i] = s.slot;
     Q.depthFlags[i] = (uint32_t)s.depth | (s.flags << 16);
     Q.rndJ[i] = s.rnd.j; Q.rndA[i] = s.rnd.a; Q.rndB[i] = s.rnd.b;
@@ -234,7 +244,6 @@ FD void path_load_ray(const PathQueue& Q, uint32_t i, PathState& s)
 FD void path_load_rest(const PathQueue& Q, uint32_t i, PathState& s)
 {
     s.pm = c3(Q.tr[i], Q.tg[i], Q.tb[i]);
-    s.acc = c3(Q.ar[i], Q.ag[i], Q.ab[i]);
     s.slot = Q.slot[i];
     uint32_t df = Q.depthFlags[i];
     s.depth = (int)(df & 0xffffu);
@@ -262,8 +271,9 @@ struct QMeta {
     uint32_t off[FRAY_MAXSEG + 1];
 };
 
-__global__ __launch_bounds__(1024) void k_scan(QMeta* m)
+__global__ __launch_bounds__(1024) void k_scan(QMeta* m0, QMeta* m1)
 {
+    QMeta* m = blockIdx.x == 0 ? m0 : m1;
     __shared__ uint32_t part[1024];
     const uint32_t nSeg = m->nSeg;
     const uint32_t per = (nSeg + 1023u) / 1024u;
@@ -297,9 +307,10 @@ FD uint32_t seg_lookup(const uint32_t* sOff, uint32_t nSeg, uint32_t chunk, uint
 
 FD void path_finish(float* __restrict__ sampleRad, DStats* st, const PathState& s, C3 add)
 {
-    C3 r = s.acc + add;
-    size_t q = (size_t)s.slot * 3;
-    sampleRad[q] = r.r; sampleRad[q + 1] = r.g; sampleRad[q + 2] = r.b;
+    if (add.r != 0 || add.g != 0 || add.b != 0) {      // x + 0 == x: nothing to do for black
+        size_t q = (size_t)s.slot * 3;
+        sampleRad[q] += add.r; sampleRad[q + 1] += add.g; sampleRad[q + 2] += add.b;
+    }
     if (s.rnd.j > 227 || s.tab.j > 227) atomicAdd(&st->rngOverflow, 1ull);
 }
 
@@ -324,7 +335,6 @@ __global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFrame F, 
             double fx = (double)((float)x + ox), fy = (double)((float)y + oy);
             if (C.dof) dof_ray(C, fx, fy, ps.tab, ps.o, ps.d); else screen_ray(C, fx, fy, ps.o, ps.d);
             ps.pm = c3(1, 1, 1);
-            ps.acc = c3(0, 0, 0);
             ps.slot = slot;
             ps.depth = 0;
             ps.flags = 0;
@@ -332,17 +342,17 @@ __global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFrame F, 
             path_store(Q, slot, ps);
         } else {
             Q.depthFlags[slot] = FRAY_DEAD;
-            size_t q = (size_t)slot * 3;
-            sampleRad[q] = 0; sampleRad[q + 1] = 0; sampleRad[q + 2] = 0;
         }
+        size_t q = (size_t)slot * 3;
+        sampleRad[q] = 0; sampleRad[q + 1] = 0; sampleRad[q + 2] = 0;
     }
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
 
 template <int ST>
-__global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, PathQueue Qin, PathQueue Qout, const QMeta* __restrict__ metaIn,
-                                                   QMeta* metaOut, float* __restrict__ sampleRad, DStats* st)
+__global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, PathQueue Qin, PathQueue Qout, ShadowQueue SQ, const QMeta* __restrict__ metaIn,
+                                                   QMeta* metaOut, QMeta* metaShadow, float* __restrict__ sampleRad, DStats* st)
 {
     __shared__ uint32_t sOff[FRAY_MAXSEG + 1];
     Cnt c = zero_cnt();
@@ -354,10 +364,12 @@ __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, 
     const uint32_t chunk = (((n + W - 1u) / W) + 63u) & ~63u;    // this launch's per-wave share = output segment size
     const uint32_t begin = w * chunk;
     const uint32_t end = begin + chunk < n ? begin + chunk : n;
-    uint32_t produced = 0;                                        // wave-uniform
+    uint32_t produced = 0, producedS = 0;                         // wave-uniform
     for (uint32_t base = begin; base < end; base += 64u) {
         const uint32_t di = base + lane;
-        bool cont = false;
+        bool cont = false, shadow = false;
+        V3 sa, sb;
+        C3 sc;
         PathState ps;
         uint32_t i = 0;
         bool live = di < end;
@@ -383,13 +395,12 @@ __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, 
                 finalize_hit<ST>(S, h, ps.o, ps.d, sh.usesUV || N.bumpTex >= 0, info);
                             apply_bump<ST>(S, h.node, info, c);
                 mt_skip(ps.tab, spawn_words(sh));                     // the discarded spawnRay (main.cpp:219-224)
-                C3 contribLight = explicit_light_sample<ST>(S, ps.d, info, ps.pm, sh, ps.rnd, ps.tab, c);
+                shadow = nee_prepare(S, ps.d, info, ps.pm, sh, ps.rnd, ps.tab, sa, sb, sc);
                 PathRay win, wout;
                 win.o = ps.o; win.d = ps.d; win.depth = ps.depth; win.flags = ps.flags;
                 C3 brdf;
                 float pdf;
                 spawn_ray(sh, info, win, ps.tab, wout, brdf, pdf);
-                ps.acc = ps.acc + contribLight;
                 if (pdf == -1.0f) {
                     path_finish(sampleRad, st, ps, c3(1, 0, 0));
                 } else if (pdf == 0.0f) {
@@ -406,9 +417,44 @@ __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, 
         const unsigned long long mask = __ballot(cont);
         if (cont) path_store(Qout, begin + produced + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), ps);
         produced += (uint32_t)__popcll(mask);
+        const unsigned long long smask = __ballot(shadow);
+        if (shadow) {
+            const uint32_t j = begin + producedS + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull));
+            SQ.ax[j] = sa.x; SQ.ay[j] = sa.y; SQ.az[j] = sa.z;
+            SQ.bx[j] = sb.x; SQ.by[j] = sb.y; SQ.bz[j] = sb.z;
+            SQ.cr[j] = sc.r; SQ.cg[j] = sc.g; SQ.cb[j] = sc.b;
+            SQ.slot[j] = ps.slot;
+        }
+        producedS += (uint32_t)__popcll(smask);
     }
-    if (lane == 0) metaOut->cnt[w] = produced;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { metaOut->chunk = chunk; metaOut->nSeg = W; }
+    if (lane == 0) { metaOut->cnt[w] = produced; metaShadow->cnt[w] = producedS; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { metaOut->chunk = chunk; metaOut->nSeg = W; metaShadow->chunk = chunk; metaShadow->nSeg = W; }
+    if (ST & 1) flush_stats(st, c);
+    if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
+}
+
+// visible() for every queued next-event segment (main.cpp:64-80, 143-144); the survivor's radiance is
+// added to its sample.  One segment per sample per bounce, so the read-modify-write has no contender.
+template <int ST>
+__global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(DScene S, ShadowQueue SQ, const QMeta* __restrict__ meta,
+                                                                        float* __restrict__ sampleRad, DStats* st)
+{
+    __shared__ uint32_t sOff[FRAY_MAXSEG + 1];
+    Cnt c = zero_cnt();
+    const uint32_t n = meta->n, nSeg = meta->nSeg, chunkIn = meta->chunk;
+    for (uint32_t k = threadIdx.x; k <= nSeg; k += blockDim.x) sOff[k] = meta->off[k];
+    __syncthreads();
+    for (uint32_t di = blockIdx.x * blockDim.x + threadIdx.x; di < n; di += gridDim.x * blockDim.x) {
+        const uint32_t i = seg_lookup(sOff, nSeg, chunkIn, di);
+        V3 a = v3(SQ.ax[i], SQ.ay[i], SQ.az[i]), b = v3(SQ.bx[i], SQ.by[i], SQ.bz[i]);
+        if (visible<ST>(S, a, b, c)) {
+            C3 add = c3(SQ.cr[i], SQ.cg[i], SQ.cb[i]);
+            if (add.r != 0 || add.g != 0 || add.b != 0) {
+                size_t q = (size_t)SQ.slot[i] * 3;
+                sampleRad[q] += add.r; sampleRad[q + 1] += add.g; sampleRad[q + 2] += add.b;
+            }
+        }
+    }
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }

@@ -151,11 +151,15 @@ def main():
     t0 = time.perf_counter()
     trace_ms = 0.0
     trace_launches = 0
+    shadow_ms = 0.0
+    shadow_launches = 0
     kernels_ms = 0.0
     for _ in range(args.steps):
         st = step()
         trace_ms += st["ms_trace"]
         trace_launches += st["trace_launches"]
+        shadow_ms += st["ms_shadow"]
+        shadow_launches += st["shadow_launches"]
         kernels_ms += st["ms_kernels"]
     torch.cuda.synchronize()
     if world > 1:
@@ -208,6 +212,12 @@ def main():
                          "note": "algorithmic bytes per SURVEY 8(d); scene tables are L2/LDS resident, so this is not HBM traffic"},
             "kernel_ms_per_step": kernels_ms / args.steps,
         }
+        if shadow_launches:
+            sb = st_counts["alg_bytes_shadow"] * args.steps / shadow_launches
+            sms = shadow_ms / shadow_launches
+            out["roofline_shadow_kernel"] = {"bound": "hbm", "kernel": "k_pt_shadow", "achieved": sb / (sms * 1e-3) / 1e9, "peak": 8000.0,
+                                             "unit": "GB/s", "frac": sb / (sms * 1e-3) / 1e9 / 8000.0, "alg_bytes_per_launch": sb,
+                                             "avg_launch_ms": sms, "launches_per_step": shadow_launches / args.steps}
         if check is not None:
             out["gathered_frame_equals_single_rank_frame"] = check
         # HBM traffic of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
@@ -215,7 +225,7 @@ def main():
         tr_path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
         if world == 1 and args.workload == "cornell_pt64" and os.path.exists(tr_path):
             try:
-                tr = json.load(open(tr_path))["void k_pt_bounce<false>"]
+                tr = json.load(open(tr_path))["void k_pt_bounce<0>"]
                 f_kb = tr["FETCH_SIZE"]["total"] / tr["FETCH_SIZE"]["launches"]
                 w_kb = tr["WRITE_SIZE"]["total"] / tr["WRITE_SIZE"]["launches"]
                 out["roofline"]["traffic"] = (f_kb + w_kb) * 1024.0

@@ -61,7 +61,7 @@ struct frayhip_scene {
     DStats* d_stats = nullptr;
     QMeta* d_qmeta = nullptr;         // [3] segment tables: ping-pong path queues + shadow queue
     hipEvent_t evA = nullptr, evB = nullptr;
-    std::vector<hipEvent_t> evPool;
+    std::vector<hipEvent_t> evPool, evPoolShadow;
 };
 
 namespace {
@@ -367,7 +367,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     S.nLights = d.n_lights;
     sc->camera = d.camera;
     sc->settings = d.settings;
-    hipMalloc((void**)&sc->d_stats, sizeof(DStats));
+    hipMalloc((void**)&sc->d_stats, 2 * sizeof(DStats));   // [0] everything but k_pt_shadow, [1] k_pt_shadow
     hipMalloc((void**)&sc->d_qmeta, 3 * sizeof(QMeta));
     hipEventCreate(&sc->evA);
     hipEventCreate(&sc->evB);
@@ -384,7 +384,8 @@ void frayhip_scene_destroy(frayhip_scene* s)
     if (s->d_qmeta) hipFree(s->d_qmeta);
     if (s->evA) hipEventDestroy(s->evA);
     if (s->evB) hipEventDestroy(s->evB);
-    for (auto e : s->evPool) hipEventDestroy(e);
+    for (auto e : s->evPool) (void)hipEventDestroy(e);
+    for (auto e : s->evPoolShadow) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -435,11 +436,12 @@ size_t shadow_bytes(size_t n)
     return 6 * r(n * 8) + 4 * r(n * 4);
 }
 
-hipEvent_t pool_event(frayhip_scene* sc, size_t i)
+hipEvent_t pool_event(std::vector<hipEvent_t>& pool, size_t i)
 {
-    while (sc->evPool.size() <= i) { hipEvent_t e; hipEventCreate(&e); sc->evPool.push_back(e); }
-    return sc->evPool[i];
+    while (pool.size() <= i) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
+    return pool[i];
 }
+hipEvent_t pool_event(frayhip_scene* sc, size_t i) { return pool_event(sc->evPool, i); }
 
 template <int ST>
 int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t* d_id, double* d_dist, hipStream_t stream, frayhip_stats* st)
@@ -468,10 +470,9 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     S.saturation = set.saturation;
     DCamera C = camera_begin_frame(sc->camera, W, H);
 
-    HIP_TRY(hipMemsetAsync(sc->d_stats, 0, sizeof(DStats), stream));
+    HIP_TRY(hipMemsetAsync(sc->d_stats, 0, 2 * sizeof(DStats), stream));
     HIP_TRY(hipEventRecord(sc->evA, stream));
-    size_t nTraceEvents = 0;
-    double algBytes = 0;
+    size_t nTraceEvents = 0, nShadowEvents = 0;
 
     if (f->mode == FRAYHIP_MODE_PRIMARY_ID) {
         if (nItems > 0) {
@@ -543,10 +544,14 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     HIP_TRY(hipEventRecord(ea, stream));
                     hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, Q[b & 1], Q[(b + 1) & 1], SQ,
                                        sc->d_qmeta + (b & 1), sc->d_qmeta + ((b + 1) & 1), sc->d_qmeta + 2, sampleRad, sc->d_stats);
-                    hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, stream, sc->d_qmeta + ((b + 1) & 1), sc->d_qmeta + 2);
-                    hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, SQ, sc->d_qmeta + 2, sampleRad, sc->d_stats);
                     HIP_TRY(hipEventRecord(eb, stream));
                     nTraceEvents += 2;
+                    hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, stream, sc->d_qmeta + ((b + 1) & 1), sc->d_qmeta + 2);
+                    hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
+                    HIP_TRY(hipEventRecord(ec, stream));
+                    hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, SQ, sc->d_qmeta + 2, sampleRad, sc->d_stats + 1);
+                    HIP_TRY(hipEventRecord(ed, stream));
+                    nShadowEvents += 2;
                 }
                 hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, stream, F, nItems, s0, cn, sampleRad, sum, d_rgb);
             }
@@ -558,33 +563,42 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->evB, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    DStats ds;
-    HIP_TRY(hipMemcpy(&ds, sc->d_stats, sizeof ds, hipMemcpyDeviceToHost));
-    if (ds.rngOverflow) {
-        set_error("frayhip_render: a camera sample left the supported envelope (path tracing: more than 227 random words per sample; Whitted: shade() nesting deeper than 40)");
+    DStats dsv[2];
+    HIP_TRY(hipMemcpy(dsv, sc->d_stats, sizeof dsv, hipMemcpyDeviceToHost));
+    if (dsv[0].rngOverflow || dsv[1].rngOverflow) {
+        set_error("frayhip_render: a camera sample left the supported envelope (path tracing: more than 227 random words per sample; Whitted: shade() nesting deeper than 40; CSG: more than 16 hits on one operand)");
         return FRAYHIP_E_UNSUPPORTED;
     }
     if (st) {
-        frayhip_stats o{};
-        o.closest_rays = ds.closest; o.shadow_rays = ds.shadow; o.node_tests = ds.node; o.kd_inner_visits = ds.kdInner;
-        o.leaf_refs = ds.leafRefs; o.tri_tests = ds.tri; o.prim_tests = ds.prim; o.smooth_hits = ds.smooth;
-        o.samples = ds.samples; o.texture_fetches = ds.tex;
-        float ms = 0;
-        hipEventElapsedTime(&ms, sc->evA, sc->evB);
-        o.ms_kernels = ms;
-        double tr = 0;
-        for (size_t i = 0; i + 1 < nTraceEvents; i += 2) {
-            float m2 = 0;
-            hipEventElapsedTime(&m2, sc->evPool[i], sc->evPool[i + 1]);
-            tr += m2;
-        }
-        o.ms_trace = tr;
-        o.trace_launches = nTraceEvents / 2;
         // SURVEY 8(d) byte model, evaluated from the counters (zero unless FRAYHIP_FRAME_STATS)
-        algBytes = 88.0 * (double)ds.closest + 73.0 * (double)ds.shadow + 168.0 * (double)ds.node + 16.0 * (double)ds.kdInner +
-                   4.0 * (double)ds.leafRefs + 120.0 * (double)ds.tri + 32.0 * (double)ds.prim + 144.0 * (double)ds.smooth +
-                   12.0 * (double)ds.tex;
-        o.alg_bytes_trace = algBytes;
+        auto model = [](const DStats& d) {
+            return 88.0 * (double)d.closest + 73.0 * (double)d.shadow + 168.0 * (double)d.node + 16.0 * (double)d.kdInner + 4.0 * (double)d.leafRefs +
+                   120.0 * (double)d.tri + 32.0 * (double)d.prim + 144.0 * (double)d.smooth + 12.0 * (double)d.tex;
+        };
+        frayhip_stats o{};
+        const DStats &a = dsv[0], &b = dsv[1];
+        o.closest_rays = a.closest + b.closest; o.shadow_rays = a.shadow + b.shadow; o.node_tests = a.node + b.node;
+        o.kd_inner_visits = a.kdInner + b.kdInner; o.leaf_refs = a.leafRefs + b.leafRefs; o.tri_tests = a.tri + b.tri;
+        o.prim_tests = a.prim + b.prim; o.smooth_hits = a.smooth + b.smooth; o.samples = a.samples + b.samples;
+        o.texture_fetches = a.tex + b.tex;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, sc->evA, sc->evB);
+        o.ms_kernels = ms;
+        auto sumEvents = [&](std::vector<hipEvent_t>& pool, size_t n) {
+            double t = 0;
+            for (size_t i = 0; i + 1 < n; i += 2) {
+                float m2 = 0;
+                (void)hipEventElapsedTime(&m2, pool[i], pool[i + 1]);
+                t += m2;
+            }
+            return t;
+        };
+        o.ms_trace = sumEvents(sc->evPool, nTraceEvents);
+        o.trace_launches = nTraceEvents / 2;
+        o.alg_bytes_trace = model(a);
+        o.ms_shadow = sumEvents(sc->evPoolShadow, nShadowEvents);
+        o.shadow_launches = nShadowEvents / 2;
+        o.alg_bytes_shadow = model(b);
         o.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         *st = o;
     }

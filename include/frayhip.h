@@ -227,9 +227,14 @@ typedef struct frayhip_stats {
     uint64_t texture_fetches;
     double   ms_total;           /* wall time of the call                                  */
     double   ms_kernels;         /* device time between first and last kernel (HIP events) */
-    double   ms_trace;           /* device time inside the dominant trace kernel(s)        */
+    double   ms_trace;           /* device time inside the dominant kernel: k_pt_bounce /
+                                    k_whitted / k_primary (HIP events around each launch)   */
     uint64_t trace_launches;     /* number of launches summed into ms_trace                */
-    double   alg_bytes_trace;    /* SURVEY 8(d) byte model evaluated on the trace kernel(s) */
+    double   alg_bytes_trace;    /* SURVEY 8(d) byte model evaluated on those launches       */
+    /* path tracing only: the next-event shadow rays run in their own kernel (k_pt_shadow) */
+    double   ms_shadow;          /* device time inside k_pt_shadow                           */
+    uint64_t shadow_launches;
+    double   alg_bytes_shadow;   /* byte model of the shadow-ray kernel                      */
 } frayhip_stats;
 
 /* ---- host scene layer (stands behind Scene::parseScene + Scene::beginRender,

@@ -499,7 +499,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 int rc = ensure_work(sc, colBytes + (size_t)nItems * spp * sizeof(uint32_t));
                 if (rc) return rc;
                 uint32_t* x397 = (uint32_t*)((unsigned char*)sc->d_work + colBytes);
-                hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * spp + 3) / 4)), dim3(256), 0, stream, F, nItems, 0, spp, x397);
+                hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * spp + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, 0, spp, x397);
                 hipEvent_t a = pool_event(sc, 0), b = pool_event(sc, 1);
                 HIP_TRY(hipEventRecord(a, stream));
                 if (sc->whittedNeedsRecursion)
@@ -536,7 +536,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 HIP_TRY(hipMemcpyAsync(sc->d_qmeta, &head, 16, hipMemcpyHostToDevice, stream));
                 const uint32_t offs[2] = {0u, head.n};
                 HIP_TRY(hipMemcpyAsync((unsigned char*)sc->d_qmeta + offsetof(QMeta, off), offs, sizeof offs, hipMemcpyHostToDevice, stream));
-                hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * cn + 3) / 4)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
+                hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * cn + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
                 hipLaunchKernelGGL(k_pt_init<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, C, F, nItems, s0, cn, Q[0],
                                    sampleRad, x397, sc->d_stats);
                 for (int b = 0; b < nBounce; b++) {

@@ -73,32 +73,37 @@ FD void dof_ray(const DCamera& C, double x, double y, G& tab, V3& o, V3& d, int 
 // ---- mt19937 seeding for a batch of camera samples -------------------------------------------------
 // x397[s * nItems + item] = x[397] of the seeding recurrence started at the contract seed of
 // (pixel(item), sample s0 + s).  The recurrence is a 397-long dependency chain of
-// shift / xor / 32-bit multiply / add, so each lane runs four independent chains at once and the
+// shift / xor / 32-bit multiply / add, so each lane runs several independent chains at once and the
 // kernel keeps its register count low enough for full occupancy.
+#ifndef FRAY_SEED_CHAINS
+#define FRAY_SEED_CHAINS 4   // 4 and 8 measure the same (1.73 ms per 44 M seeds): the kernel is bound by v_mul_lo_u32 issue, not latency
+#endif
 __global__ __launch_bounds__(256) void k_seed(DFrame F, int nItems, int s0, int chunk, uint32_t* __restrict__ x397)
 {
+    constexpr int NC = FRAY_SEED_CHAINS;
     const uint32_t total = (uint32_t)nItems * (uint32_t)chunk;
-    const uint32_t quads = (total + 3u) / 4u;
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x) {
-        uint32_t b[4], slot[4];
-        bool ok[4];
-        for (int k = 0; k < 4; k++) {
+    const uint32_t groups = (total + NC - 1u) / NC;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < groups; q += gridDim.x * blockDim.x) {
+        uint32_t b[NC], slot[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
             // strided so that consecutive lanes write consecutive words
-            slot[k] = q + (uint32_t)k * quads;
-            ok[k] = slot[k] < total;
+            slot[k] = q + (uint32_t)k * groups;
             b[k] = 0;
-            if (ok[k]) {
+            if (slot[k] < total) {
                 int item = (int)(slot[k] % (uint32_t)nItems), s = (int)(slot[k] / (uint32_t)nItems);
                 int x, y;
-                ok[k] = item_pixel(F, item, x, y);
+                item_pixel(F, item, x, y);
                 b[k] = sample_seed(F.seed, (uint32_t)y * (uint32_t)F.W + (uint32_t)x, (uint32_t)(s0 + s));
             }
         }
 #pragma unroll 1
         for (uint32_t i = 1; i <= 397; i++) {
-            b[0] = mt_lcg(b[0], i); b[1] = mt_lcg(b[1], i); b[2] = mt_lcg(b[2], i); b[3] = mt_lcg(b[3], i);
+#pragma unroll
+            for (int k = 0; k < NC; k++) b[k] = mt_lcg(b[k], i);
         }
-        for (int k = 0; k < 4; k++) if (slot[k] < total) x397[slot[k]] = b[k];
+#pragma unroll
+        for (int k = 0; k < NC; k++) if (slot[k] < total) x397[slot[k]] = b[k];
     }
 }
 

@@ -342,7 +342,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     for (int i = 0; i < d.n_textures; i++) tex[i].texels = (const FRAY_RO float*)(base + oTexels) + d.textures[i].texel_offset;
     if (!tex.empty()) memcpy(A.host.data() + oTex, tex.data(), tex.size() * sizeof(DTexture));
     hipError_t e = hipMemcpy(sc->d_arena, A.host.data(), A.host.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { set_error(std::string("frayhip_scene_create: upload failed: ") + hipGetErrorString(e)); hipFree(sc->d_arena); delete sc; return FRAYHIP_E_NODEVICE; }
+    if (e != hipSuccess) { set_error(std::string("frayhip_scene_create: upload failed: ") + hipGetErrorString(e)); (void)hipFree(sc->d_arena); delete sc; return FRAYHIP_E_NODEVICE; }
     sc->arena_bytes = A.host.size();
 
     DScene& S = sc->S;
@@ -367,10 +367,13 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     S.nLights = d.n_lights;
     sc->camera = d.camera;
     sc->settings = d.settings;
-    hipMalloc((void**)&sc->d_stats, 2 * sizeof(DStats));   // [0] everything but k_pt_shadow, [1] k_pt_shadow
-    hipMalloc((void**)&sc->d_qmeta, 3 * sizeof(QMeta));
-    hipEventCreate(&sc->evA);
-    hipEventCreate(&sc->evB);
+    // [0] everything but k_pt_shadow, [1] k_pt_shadow
+    if (hipMalloc((void**)&sc->d_stats, 2 * sizeof(DStats)) != hipSuccess || hipMalloc((void**)&sc->d_qmeta, 3 * sizeof(QMeta)) != hipSuccess ||
+        hipEventCreate(&sc->evA) != hipSuccess || hipEventCreate(&sc->evB) != hipSuccess) {
+        set_error("frayhip_scene_create: could not allocate the per-scene device state");
+        frayhip_scene_destroy(sc);
+        return FRAYHIP_E_NOMEM;
+    }
     *out = sc;
     return FRAYHIP_OK;
 }
@@ -378,12 +381,12 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
 void frayhip_scene_destroy(frayhip_scene* s)
 {
     if (!s) return;
-    if (s->d_arena) hipFree(s->d_arena);
-    if (s->d_work) hipFree(s->d_work);
-    if (s->d_stats) hipFree(s->d_stats);
-    if (s->d_qmeta) hipFree(s->d_qmeta);
-    if (s->evA) hipEventDestroy(s->evA);
-    if (s->evB) hipEventDestroy(s->evB);
+    if (s->d_arena) (void)hipFree(s->d_arena);
+    if (s->d_work) (void)hipFree(s->d_work);
+    if (s->d_stats) (void)hipFree(s->d_stats);
+    if (s->d_qmeta) (void)hipFree(s->d_qmeta);
+    if (s->evA) (void)hipEventDestroy(s->evA);
+    if (s->evB) (void)hipEventDestroy(s->evB);
     for (auto e : s->evPool) (void)hipEventDestroy(e);
     for (auto e : s->evPoolShadow) (void)hipEventDestroy(e);
     delete s;
@@ -396,7 +399,7 @@ namespace {
 int ensure_work(frayhip_scene* sc, size_t bytes)
 {
     if (sc->work_bytes >= bytes) return FRAYHIP_OK;
-    if (sc->d_work) hipFree(sc->d_work);
+    if (sc->d_work) (void)hipFree(sc->d_work);
     sc->d_work = nullptr;
     sc->work_bytes = 0;
     if (hipMalloc(&sc->d_work, bytes) != hipSuccess) { set_error("frayhip_render: out of device memory for the path queues"); return FRAYHIP_E_NOMEM; }
@@ -625,20 +628,23 @@ int frayhip_render(frayhip_scene* s, const frayhip_frame* f, float* rgb, int32_t
     const size_t n = (size_t)s->settings.frameWidth * s->settings.frameHeight;
     float* d_rgb = nullptr; int32_t* d_id = nullptr; double* d_dist = nullptr;
     int rc = FRAYHIP_OK;
-    auto cleanup = [&]() { if (d_rgb) hipFree(d_rgb); if (d_id) hipFree(d_id); if (d_dist) hipFree(d_dist); };
+    auto cleanup = [&]() { if (d_rgb) (void)hipFree(d_rgb); if (d_id) (void)hipFree(d_id); if (d_dist) (void)hipFree(d_dist); };
     if (rgb && hipMalloc((void**)&d_rgb, n * 12) != hipSuccess) rc = FRAYHIP_E_NOMEM;
     if (!rc && hit_id && hipMalloc((void**)&d_id, n * 4) != hipSuccess) rc = FRAYHIP_E_NOMEM;
     if (!rc && hit_dist && hipMalloc((void**)&d_dist, n * 8) != hipSuccess) rc = FRAYHIP_E_NOMEM;
     if (rc) { set_error("frayhip_render: hipMalloc failed"); cleanup(); return rc; }
     // pixels outside this call's buckets keep what the caller had in the buffers
-    if (d_rgb) hipMemcpy(d_rgb, rgb, n * 12, hipMemcpyHostToDevice);
-    if (d_id) hipMemcpy(d_id, hit_id, n * 4, hipMemcpyHostToDevice);
-    if (d_dist) hipMemcpy(d_dist, hit_dist, n * 8, hipMemcpyHostToDevice);
+    hipError_t ce = hipSuccess;
+    if (d_rgb && ce == hipSuccess) ce = hipMemcpy(d_rgb, rgb, n * 12, hipMemcpyHostToDevice);
+    if (d_id && ce == hipSuccess) ce = hipMemcpy(d_id, hit_id, n * 4, hipMemcpyHostToDevice);
+    if (d_dist && ce == hipSuccess) ce = hipMemcpy(d_dist, hit_dist, n * 8, hipMemcpyHostToDevice);
+    if (ce != hipSuccess) { set_error(std::string("frayhip_render: host-to-device copy failed: ") + hipGetErrorString(ce)); cleanup(); return FRAYHIP_E_NODEVICE; }
     rc = frayhip_render_device(s, f, d_rgb, d_id, d_dist, nullptr, st);
     if (!rc) {
-        if (d_rgb) hipMemcpy(rgb, d_rgb, n * 12, hipMemcpyDeviceToHost);
-        if (d_id) hipMemcpy(hit_id, d_id, n * 4, hipMemcpyDeviceToHost);
-        if (d_dist) hipMemcpy(hit_dist, d_dist, n * 8, hipMemcpyDeviceToHost);
+        if (d_rgb && ce == hipSuccess) ce = hipMemcpy(rgb, d_rgb, n * 12, hipMemcpyDeviceToHost);
+        if (d_id && ce == hipSuccess) ce = hipMemcpy(hit_id, d_id, n * 4, hipMemcpyDeviceToHost);
+        if (d_dist && ce == hipSuccess) ce = hipMemcpy(hit_dist, d_dist, n * 8, hipMemcpyDeviceToHost);
+        if (ce != hipSuccess) { set_error(std::string("frayhip_render: device-to-host copy failed: ") + hipGetErrorString(ce)); rc = FRAYHIP_E_NODEVICE; }
     }
     cleanup();
     return rc;

@@ -1,4 +1,4 @@
-"""Ad-hoc GPU bring-up script (not a pytest file): HIP path vs oracle on a few scenes."""
+"""Ad-hoc GPU bring-up script: HIP path vs oracle on a few scenes."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

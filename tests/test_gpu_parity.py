@@ -453,3 +453,28 @@ def test_gpu_colour_vs_reference_fixture(fray, gpu, path):
     img, _ = s.render(seed=int(z["seed"]))
     assert np.all(rms(img, z["image"]) <= RMS_TOL), rms(img, z["image"])
     s.close()
+
+
+@pytest.mark.parametrize("scene,W,H,over,strip", [
+    ("smallpt.fray", 4096, 4096, dict(gi=1, numPaths=2), (123, 500)),                       # BASELINE configs[4] frame size
+    ("forest.fray", 1920, 1080, dict(wantAA=0, dof=1, numDOFSamples=4, interactive=0), (7, 40)),   # configs[3]: KD meshes, DOF, cubemap
+    ("zaphod.fray", 1920, 1080, dict(wantAA=0, dof=0), (11, 40)),                             # configs[1]
+])
+def test_full_size_frames_of_the_other_configs(fray, abi, oracle, gpu, scene, W, H, over, strip):
+    """Full BASELINE frame sizes: determinism plus a strided strip of buckets against the oracle."""
+    s = open_scene(fray, scene, W, H, **over)
+    s.beginRender()
+    a, _ = s.render(seed=42)
+    b, _ = s.render(seed=42)
+    assert np.array_equal(a, b) and np.all(np.isfinite(a))
+    first, stride = strip
+    ref, _ = oracle.render(s.desc, abi.MODE_RENDER, seed=42, bucket_first=first, bucket_stride=stride)
+    BW, BH = (W - 1) // 48 + 1, (H - 1) // 48 + 1
+    mask = np.zeros((H, W), bool)
+    for bk in range(first, BW * BH, stride):
+        bx, by = bk % BW, bk // BW
+        mask[by * 48:by * 48 + 48, bx * 48:bx * 48 + 48] = True
+    assert mask.sum() > 20000
+    d = (a[mask].astype(np.float64) - ref[mask]) ** 2
+    assert np.all(np.sqrt(d.mean(axis=0)) <= RMS_TOL), np.sqrt(d.mean(axis=0))
+    s.close()

@@ -260,6 +260,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
                 o.triBegin = K.tri_begin; o.triCount = K.tri_count; o.pad = 0;
                 o.lo = o.hi = 0;
                 if (K.axis != 3) {
+                    o.pad = (m.kdnodes[K.child0].axis == 3 ? 1 : 0) | (m.kdnodes[K.child0 + 1].axis == 3 ? 2 : 0);
                     o.lo = boxes[n].lo[K.axis];
                     o.hi = boxes[n].hi[K.axis];
                     boxes[K.child0] = boxes[n];
@@ -517,7 +518,8 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, ((size_t)1 << 26) / (size_t)nItems);
             if (chunk > spp) chunk = spp;
             const size_t nPaths = (size_t)nItems * chunk;
-            const size_t nQueue = nPaths + (size_t)FRAY_MAXSEG * 128;   // per-wave segments round their share up to 64
+            // per-wave segments round their share up to a multiple of 64: one extra wave-load per wave of the grid
+            const size_t nQueue = nPaths + (size_t)grid_for(nPaths) * 4 * 128;
             const size_t need = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + (size_t)nItems * 12 + nPaths * 4 + 8192;
             int rc = ensure_work(sc, need);
             if (rc) return rc;

@@ -56,7 +56,8 @@ struct DTriAttr {      // 168 B, winning triangle only
 
 struct DKd {           // 48 B
     double split, lo, hi;
-    int32_t child0, parent, axis, triBegin, triCount, pad;
+    int32_t child0, parent, axis, triBegin, triCount;
+    int32_t pad;       // inner node: bit c set = child c is a leaf (saves the walk a dependent load)
 };
 
 struct DMesh {

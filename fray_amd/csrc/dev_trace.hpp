@@ -154,52 +154,88 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
         return found;
     }
     // ---- stackless KD walk (Mesh::intersectKD, mesh.cpp:357-394) ----
+    // A lane's position is "(P, k): about to test child option k of inner node P, with P's box in
+    // registers" (k = 0: the near child, picked by ray.start[axis] < split; k = 1: the other one).
+    // The loop is written while-while: an inner loop whose every iteration is exactly one box test
+    // for every lane still walking, until the lane stands in a leaf (or has left the root); then
+    // the leaf's triangles; then back to walking.  Lanes of a wave therefore run box tests together
+    // and triangle tests together instead of interleaving them.  Per lane the sequence of box
+    // tests, leaves and triangles is the reference's recursion, step for step.
     const FRAY_RO DKd* kd = M.kd;
-    int node = 0;
-    bool down = true;          // true: entering `node`; false: leaving it upwards
+    int P = 0, k = 0;
+    int axis = kd[0].axis, child0 = kd[0].child0, leafMask = kd[0].pad;
+    double split = kd[0].split;
+    bump<ST>(c.kdInner);
+    bool alive = true;
     for (;;) {
-        if (down) {
-            const int axis = kd[node].axis;
-            if (axis == 3) {   // leaf: test every triangle, accept iff found && inside(leaf box, ip)
-                const int beg = kd[node].triBegin, cnt = kd[node].triCount;
-                bool found = false;
-                for (int k = 0; k < cnt; k++) {
-                    bump<ST>(c.leafRefs);
-                    int idx = M.refs[beg + k];
-                    if (tri_test<ST>(M.tris + idx, culling, s, d, gamma, l2, l3, c)) { found = true; tri = idx; }
+        int leaf = -1;
+        int node = 0;                  // the node whose options are exhausted (climb start)
+        while (alive && leaf < 0) {
+            const int first = comp(s, axis) < split ? 0 : 1;
+            const int ch = k == 0 ? first : 1 - first;
+            Box6 cb = box;                                // BBox::split, bbox.h:205-211
+            if (ch == 0) box_set_hi(cb, axis, split); else box_set_lo(cb, axis, split);
+            bool climb = false;
+            if (box_test(cb, s, d, rd)) {
+                box = cb;
+                const int child = child0 + ch;
+                if ((leafMask >> ch) & 1) {
+                    leaf = child;
+                } else {
+                    P = child; k = 0;
+                    axis = kd[P].axis; child0 = kd[P].child0; leafMask = kd[P].pad; split = kd[P].split;
+                    bump<ST>(c.kdInner);
                 }
-                if (found && box_inside(box, s + d * gamma)) return true;
-                down = false;
-                continue;
+            } else if (k == 0) {
+                k = 1;
+            } else {
+                climb = true;
+                node = P;
             }
-            bump<ST>(c.kdInner);
-            const double split = kd[node].split;
-            const int child0 = kd[node].child0;
-            const int first = comp(s, axis) < split ? 0 : 1;
-            bool went = false;
-            for (int t = 0; t < 2 && !went; t++) {
-                const int ch = t == 0 ? first : 1 - first;
-                Box6 cb = box;                        // BBox::split, bbox.h:205-211
-                if (ch == 0) box_set_hi(cb, axis, split); else box_set_lo(cb, axis, split);
-                if (box_test(cb, s, d, rd)) { box = cb; node = child0 + ch; went = true; }
+            if (climb) {
+                // both children of P are done: go up until a parent still has its second child to try
+                for (;;) {
+                    const int p = kd[node].parent;
+                    if (p < 0) { alive = false; break; }          // back above the root: no leaf accepted
+                    const int pa = kd[p].axis;
+                    const double ps = kd[p].split;
+                    const int pc = kd[p].child0;
+                    box_set_lo(box, pa, kd[p].lo);                  // the parent's box again
+                    box_set_hi(box, pa, kd[p].hi);
+                    const int pfirst = comp(s, pa) < ps ? 0 : 1;
+                    if (node - pc == pfirst) { P = p; k = 1; axis = pa; split = ps; child0 = pc; leafMask = kd[p].pad; break; }
+                    node = p;
+                }
             }
-            if (!went) down = false;
-        } else {
-            const int p = kd[node].parent;
-            if (p < 0) return false;      // back above the root: no leaf accepted
-            const int axis = kd[p].axis;
-            const double split = kd[p].split;
-            box_set_lo(box, axis, kd[p].lo);          // parent's box again
-            box_set_hi(box, axis, kd[p].hi);
-            const int which = node - kd[p].child0;
-            const int first = comp(s, axis) < split ? 0 : 1;
-            node = p;
-            if (which == first) {                     // the other child is still to be visited
-                const int ch = 1 - first;
-                Box6 cb = box;
-                if (ch == 0) box_set_hi(cb, axis, split); else box_set_lo(cb, axis, split);
-                if (box_test(cb, s, d, rd)) { box = cb; node = kd[p].child0 + ch; down = true; }
+        }
+        if (!alive) return false;
+        // ---- leaf: test every triangle, accept iff found && inside(leaf box, ip)
+        {
+            const int beg = kd[leaf].triBegin, cnt = kd[leaf].triCount;
+            bool found = false;
+            for (int t = 0; t < cnt; t++) {
+                bump<ST>(c.leafRefs);
+                int idx = M.refs[beg + t];
+                if (tri_test<ST>(M.tris + idx, culling, s, d, gamma, l2, l3, c)) { found = true; tri = idx; }
             }
+            if (found && box_inside(box, s + d * gamma)) return true;
+        }
+        // the leaf is done: continue with its parent's remaining option (the box is restored while climbing)
+        {
+            int nd = leaf;
+            for (;;) {
+                const int p = kd[nd].parent;
+                if (p < 0) { alive = false; break; }
+                const int pa = kd[p].axis;
+                const double ps = kd[p].split;
+                const int pc = kd[p].child0;
+                box_set_lo(box, pa, kd[p].lo);
+                box_set_hi(box, pa, kd[p].hi);
+                const int pfirst = comp(s, pa) < ps ? 0 : 1;
+                if (nd - pc == pfirst) { P = p; k = 1; axis = pa; split = ps; child0 = pc; leafMask = kd[p].pad; break; }
+                nd = p;
+            }
+            if (!alive) return false;
         }
     }
 }

@@ -256,11 +256,11 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
             for (int n = 0; n < m.n_kdnodes; n++) {   // parents precede children in the array
                 const frayhip_kdnode& K = m.kdnodes[n];
                 DKd& o = kd[n];
-                o.split = K.split; o.child0 = K.child0; o.parent = K.parent; o.axis = K.axis;
+                o.split = K.split; o.child0 = K.child0; o.parent = K.parent; o.meta = K.axis;
                 o.triBegin = K.tri_begin; o.triCount = K.tri_count; o.pad = 0;
                 o.lo = o.hi = 0;
                 if (K.axis != 3) {
-                    o.pad = (m.kdnodes[K.child0].axis == 3 ? 1 : 0) | (m.kdnodes[K.child0 + 1].axis == 3 ? 2 : 0);
+                    o.meta |= (m.kdnodes[K.child0].axis == 3 ? 4 : 0) | (m.kdnodes[K.child0 + 1].axis == 3 ? 8 : 0);
                     o.lo = boxes[n].lo[K.axis];
                     o.hi = boxes[n].hi[K.axis];
                     boxes[K.child0] = boxes[n];

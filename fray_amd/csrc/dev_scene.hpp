@@ -55,9 +55,11 @@ struct DTriAttr {      // 168 B, winning triangle only
 };
 
 struct DKd {           // 48 B
-    double split, lo, hi;
-    int32_t child0, parent, axis, triBegin, triCount;
-    int32_t pad;       // inner node: bit c set = child c is a leaf (saves the walk a dependent load)
+    double split;      // } the 16 bytes a descending step reads
+    int32_t child0;    // }
+    int32_t meta;      // } axis (bits 0-1; 3 = leaf) | inner: bit 2+c set = child c is a leaf
+    double lo, hi;     // the node's own box extent along its split axis (read when climbing back to it)
+    int32_t parent, triBegin, triCount, pad;
 };
 
 struct DMesh {

@@ -163,7 +163,8 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
     // tests, leaves and triangles is the reference's recursion, step for step.
     const FRAY_RO DKd* kd = M.kd;
     int P = 0, k = 0;
-    int axis = kd[0].axis, child0 = kd[0].child0, leafMask = kd[0].pad;
+    int meta = kd[0].meta, child0 = kd[0].child0;
+    int axis = meta & 3, leafMask = meta >> 2;
     double split = kd[0].split;
     bump<ST>(c.kdInner);
     bool alive = true;
@@ -183,7 +184,8 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
                     leaf = child;
                 } else {
                     P = child; k = 0;
-                    axis = kd[P].axis; child0 = kd[P].child0; leafMask = kd[P].pad; split = kd[P].split;
+                    meta = kd[P].meta; child0 = kd[P].child0; split = kd[P].split;
+                    axis = meta & 3; leafMask = meta >> 2;
                     bump<ST>(c.kdInner);
                 }
             } else if (k == 0) {
@@ -197,13 +199,13 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
                 for (;;) {
                     const int p = kd[node].parent;
                     if (p < 0) { alive = false; break; }          // back above the root: no leaf accepted
-                    const int pa = kd[p].axis;
+                    const int pm = kd[p].meta, pa = pm & 3;
                     const double ps = kd[p].split;
                     const int pc = kd[p].child0;
                     box_set_lo(box, pa, kd[p].lo);                  // the parent's box again
                     box_set_hi(box, pa, kd[p].hi);
                     const int pfirst = comp(s, pa) < ps ? 0 : 1;
-                    if (node - pc == pfirst) { P = p; k = 1; axis = pa; split = ps; child0 = pc; leafMask = kd[p].pad; break; }
+                    if (node - pc == pfirst) { P = p; k = 1; axis = pa; split = ps; child0 = pc; leafMask = pm >> 2; break; }
                     node = p;
                 }
             }
@@ -226,13 +228,13 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
             for (;;) {
                 const int p = kd[nd].parent;
                 if (p < 0) { alive = false; break; }
-                const int pa = kd[p].axis;
+                const int pm = kd[p].meta, pa = pm & 3;
                 const double ps = kd[p].split;
                 const int pc = kd[p].child0;
                 box_set_lo(box, pa, kd[p].lo);
                 box_set_hi(box, pa, kd[p].hi);
                 const int pfirst = comp(s, pa) < ps ? 0 : 1;
-                if (nd - pc == pfirst) { P = p; k = 1; axis = pa; split = ps; child0 = pc; leafMask = kd[p].pad; break; }
+                if (nd - pc == pfirst) { P = p; k = 1; axis = pa; split = ps; child0 = pc; leafMask = pm >> 2; break; }
                 nd = p;
             }
             if (!alive) return false;

@@ -81,9 +81,11 @@ FD bool box_test(const Box6& b, V3 s, V3 d, V3 rd)
     BoxDim a = box_dim(s.x, d.x, rd.x, b.lox, b.hix, s.y, d.y, b.loy, b.hiy, s.z, d.z, b.loz, b.hiz);
     res |= alive & a.hit;
     alive &= !a.rej & !a.hit;
+    if (!__any(alive)) return res;          // wave-uniform: every lane is decided
     a = box_dim(s.y, d.y, rd.y, b.loy, b.hiy, s.x, d.x, b.lox, b.hix, s.z, d.z, b.loz, b.hiz);
     res |= alive & a.hit;
     alive &= !a.rej & !a.hit;
+    if (!__any(alive)) return res;
     a = box_dim(s.z, d.z, rd.z, b.loz, b.hiz, s.x, d.x, b.lox, b.hix, s.y, d.y, b.loy, b.hiy);
     res |= alive & a.hit;
     return res;
@@ -109,6 +111,7 @@ FD bool tri_test(const FRAY_RO DTri* T, int culling, V3 s, V3 d, double& best, d
     V3 D = -d;
     double Dcr = dot(N, D);
     ok &= !(fabs(Dcr) < 1e-12);
+    if (!__any(ok)) return false;           // wave-uniform: every lane culled this triangle
     double rDcr = 1 / Dcr;
     V3 H = s - A;
     double gamma = dot(N, H) * rDcr;

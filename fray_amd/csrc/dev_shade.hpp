@@ -365,29 +365,3 @@ FD bool nee_prepare(const DScene& S, V3 rayDir, const HitInfo& info, C3 pm, cons
     contrib = Le * pm * brdfAtPoint / chooseLightProb;
     return true;
 }
-
-// explicitLightSample, main.cpp:118-169 (fused form, used by nothing on the hot path any more).  `rnd` is the worker's local generator, `tab` the
-// per-thread table generator (RectLight::getNthSample draws from the latter).
-template <int ST>
-FD C3 explicit_light_sample(const DScene& S, V3 rayDir, const HitInfo& info, C3 pm, const FRAY_RO DShader& sh, Mt& rnd, Mt& tab, Cnt& c)
-{
-    if (S.nLights == 0) return c3(0, 0, 0);
-    int lightIdx = rng_int0(rnd, S.nLights - 1);
-    const FRAY_RO DLight& L = S.lights[lightIdx];
-    V3 x = info.ip;
-    double solidAngle = light_solid_angle(L, x);
-    if (solidAngle == 0) return c3(0, 0, 0);
-    int randSample = rng_int0(rnd, light_num_samples(L) - 1);
-    V3 pointOnLight;
-    C3 unused;
-    light_nth_sample(L, randSample, x, tab, pointOnLight, unused);
-    if (!visible<ST>(S, x + info.norm * 1e-6, pointOnLight, c)) return c3(0, 0, 0);
-    C3 Le = light_color(L);
-    V3 w_out = normalized(pointOnLight - x);
-    C3 brdfAtPoint = brdf_eval(sh, info, w_out);
-    if (intensity(brdfAtPoint) == 0) return c3(0, 0, 0);
-    float probHitLightArea = (float)(1.0f / solidAngle);
-    float probPickThisLight = 1.0f / (float)S.nLights;
-    float chooseLightProb = probHitLightArea * probPickThisLight;
-    return Le * pm * brdfAtPoint / chooseLightProb;
-}

@@ -488,11 +488,6 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
         }
     } else if (f->mode == FRAYHIP_MODE_RENDER) {
         if (!d_rgb) { set_error("frayhip_render: MODE_RENDER needs an rgb buffer"); return FRAYHIP_E_ARG; }
-        if (sc->camera.stereoSeparation > 0 && set.gi) {
-            // the right eye's path continues the left eye's random stream: inherently sequential
-            set_error("frayhip_render: stereo cameras are not implemented for path tracing on the device path yet");
-            return FRAYHIP_E_UNSUPPORTED;
-        }
         if (!set.gi) {
             if (!F.jitter && spp > 5) { set_error("frayhip_render: bad sample count"); return FRAYHIP_E_ARG; }
             if (nItems > 0) {
@@ -520,7 +515,9 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             const size_t nPaths = (size_t)nItems * chunk;
             // per-wave segments round their share up to a multiple of 64: one extra wave-load per wave of the grid
             const size_t nQueue = nPaths + (size_t)grid_for(nPaths) * 4 * 128;
-            const size_t need = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + (size_t)nItems * 12 + nPaths * 4 + 8192;
+            const bool stereo = sc->camera.stereoSeparation > 0;
+            const size_t need = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + (size_t)nItems * 12 + nPaths * 4 + 8192 +
+                                (stereo ? nPaths * (12 + 6 * 8 + 6 * 4) + 16 * 256 : 0);
             int rc = ensure_work(sc, need);
             if (rc) return rc;
             PathQueue Q[2];
@@ -531,34 +528,46 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             p = carve_shadow(p, nQueue, SQ);
             float* sampleRad = (float*)p; p += (nPaths * 12 + 255) / 256 * 256;
             float* sum = (float*)p; p += ((size_t)nItems * 12 + 255) / 256 * 256;
-            uint32_t* x397 = (uint32_t*)p;
+            uint32_t* x397 = (uint32_t*)p; p += (nPaths * 4 + 255) / 256 * 256;
+            StereoBuf SB{}, SBnone{};
+            float* sampleRadR = nullptr;
+            if (stereo) {
+                sampleRadR = (float*)p; p += (nPaths * 12 + 255) / 256 * 256;
+                for (int k = 0; k < 6; k++) { SB.r[k] = (double*)p; p += (nPaths * 8 + 255) / 256 * 256; }
+                for (int k = 0; k < 6; k++) { SB.g[k] = (uint32_t*)p; p += (nPaths * 4 + 255) / 256 * 256; }
+            }
             const int nBounce = set.maxTraceDepth + 2;
             for (int s0 = 0; s0 < spp; s0 += chunk) {
                 const int cn = std::min(chunk, spp - s0);
-                // queue 0 is dense: one segment holding every slot of the batch
-                QMeta head{};
-                head.n = (uint32_t)((size_t)nItems * cn); head.chunk = head.n; head.nSeg = 1;
-                HIP_TRY(hipMemcpyAsync(sc->d_qmeta, &head, 16, hipMemcpyHostToDevice, stream));
-                const uint32_t offs[2] = {0u, head.n};
-                HIP_TRY(hipMemcpyAsync((unsigned char*)sc->d_qmeta + offsetof(QMeta, off), offs, sizeof offs, hipMemcpyHostToDevice, stream));
                 hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * cn + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
-                hipLaunchKernelGGL(k_pt_init<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, C, F, nItems, s0, cn, Q[0],
-                                   sampleRad, x397, sc->d_stats);
-                for (int b = 0; b < nBounce; b++) {
-                    hipEvent_t ea = pool_event(sc, nTraceEvents), eb = pool_event(sc, nTraceEvents + 1);
-                    HIP_TRY(hipEventRecord(ea, stream));
-                    hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, Q[b & 1], Q[(b + 1) & 1], SQ,
-                                       sc->d_qmeta + (b & 1), sc->d_qmeta + ((b + 1) & 1), sc->d_qmeta + 2, sampleRad, sc->d_stats);
-                    HIP_TRY(hipEventRecord(eb, stream));
-                    nTraceEvents += 2;
-                    hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, stream, sc->d_qmeta + ((b + 1) & 1), sc->d_qmeta + 2);
-                    hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
-                    HIP_TRY(hipEventRecord(ec, stream));
-                    hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, SQ, sc->d_qmeta + 2, sampleRad, sc->d_stats + 1);
-                    HIP_TRY(hipEventRecord(ed, stream));
-                    nShadowEvents += 2;
+                for (int eye = 0; eye < (stereo ? 2 : 1); eye++) {
+                    // queue 0 is dense: one segment holding every slot of the batch
+                    QMeta head{};
+                    head.n = (uint32_t)((size_t)nItems * cn); head.chunk = head.n; head.nSeg = 1;
+                    HIP_TRY(hipMemcpyAsync(sc->d_qmeta, &head, 16, hipMemcpyHostToDevice, stream));
+                    const uint32_t offs[2] = {0u, head.n};
+                    HIP_TRY(hipMemcpyAsync((unsigned char*)sc->d_qmeta + offsetof(QMeta, off), offs, sizeof offs, hipMemcpyHostToDevice, stream));
+                    float* rad = eye == 0 ? sampleRad : sampleRadR;
+                    // left pass of a stereo frame saves generator cursors at path end; mono and the right pass do not
+                    const StereoBuf& save = (stereo && eye == 0) ? SB : SBnone;
+                    hipLaunchKernelGGL(k_pt_init<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, C, F, nItems, s0, cn, Q[0],
+                                       rad, x397, SB, eye, sc->d_stats);
+                    for (int b = 0; b < nBounce; b++) {
+                        hipEvent_t ea = pool_event(sc, nTraceEvents), eb = pool_event(sc, nTraceEvents + 1);
+                        HIP_TRY(hipEventRecord(ea, stream));
+                        hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, Q[b & 1], Q[(b + 1) & 1], SQ,
+                                           sc->d_qmeta + (b & 1), sc->d_qmeta + ((b + 1) & 1), sc->d_qmeta + 2, rad, save, sc->d_stats);
+                        HIP_TRY(hipEventRecord(eb, stream));
+                        nTraceEvents += 2;
+                        hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, stream, sc->d_qmeta + ((b + 1) & 1), sc->d_qmeta + 2);
+                        hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
+                        HIP_TRY(hipEventRecord(ec, stream));
+                        hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, SQ, sc->d_qmeta + 2, rad, sc->d_stats + 1);
+                        HIP_TRY(hipEventRecord(ed, stream));
+                        nShadowEvents += 2;
+                    }
                 }
-                hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, stream, F, nItems, s0, cn, sampleRad, sum, d_rgb);
+                hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, stream, F, C, set.saturation, nItems, s0, cn, sampleRad, sampleRadR, sum, d_rgb);
             }
         }
     } else {

@@ -310,8 +310,21 @@ FD uint32_t seg_lookup(const uint32_t* sOff, uint32_t nSeg, uint32_t chunk, uint
     return lo * chunk + (i - sOff[lo]);
 }
 
-FD void path_finish(float* __restrict__ sampleRad, DStats* st, const PathState& s, C3 add)
+// Stereo path tracing (raytraceSinglePixel, main.cpp:306-317): both eye rays are generated first, the
+// left path is traced, and the right path CONTINUES both random generators where the left path stopped.
+// So the left pass parks the right eye's ray and, when a left path ends, its generator cursors, per sample
+// slot; the right pass starts from those.  g[0] == nullptr: nothing to save (mono, or the right pass).
+struct StereoBuf {
+    double* r[6];      // right-eye ray: origin xyz, direction xyz
+    uint32_t* g[6];    // rnd {j, a, b}, tab {j, a, b} at the end of the left path
+};
+
+FD void path_finish(float* __restrict__ sampleRad, DStats* st, const PathState& s, C3 add, const StereoBuf& SB)
 {
+    if (SB.g[0]) {
+        SB.g[0][s.slot] = s.rnd.j; SB.g[1][s.slot] = s.rnd.a; SB.g[2][s.slot] = s.rnd.b;
+        SB.g[3][s.slot] = s.tab.j; SB.g[4][s.slot] = s.tab.a; SB.g[5][s.slot] = s.tab.b;
+    }
     if (add.r != 0 || add.g != 0 || add.b != 0) {      // x + 0 == x: nothing to do for black
         size_t q = (size_t)s.slot * 3;
         sampleRad[q] += add.r; sampleRad[q + 1] += add.g; sampleRad[q + 2] += add.b;
@@ -324,21 +337,36 @@ FD void path_finish(float* __restrict__ sampleRad, DStats* st, const PathState& 
 #define FRAY_DEAD 0xffffffffu
 template <int ST>
 __global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFrame F, int nItems, int s0, int chunk, PathQueue Q,
-                                                 float* __restrict__ sampleRad, const uint32_t* __restrict__ x397, DStats* st)
+                                                 float* __restrict__ sampleRad, const uint32_t* __restrict__ x397, StereoBuf SB, int eye, DStats* st)
 {
     Cnt c = zero_cnt();
     const uint32_t total = (uint32_t)nItems * (uint32_t)chunk;
+    const bool stereo = C.stereoSeparation > 0;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += gridDim.x * blockDim.x) {
         int item = (int)(slot % (uint32_t)nItems), s = (int)(slot / (uint32_t)nItems);
         int x, y;
         if (item_pixel(F, item, x, y)) {
             PathState ps;
-            const uint32_t p = (uint32_t)y * (uint32_t)F.W + (uint32_t)x;
-            ps.rnd = mt_seed_with(sample_seed(F.seed, p, (uint32_t)(s0 + s)), x397[slot]);
-            ps.tab = ps.rnd;
-            float ox = rng_float(ps.rnd), oy = rng_float(ps.rnd);           // gi: always jittered (main.cpp:351-353)
-            double fx = (double)((float)x + ox), fy = (double)((float)y + oy);
-            if (C.dof) dof_ray(C, fx, fy, ps.tab, ps.o, ps.d); else screen_ray(C, fx, fy, ps.o, ps.d);
+            if (eye == 0) {
+                const uint32_t p = (uint32_t)y * (uint32_t)F.W + (uint32_t)x;
+                ps.rnd = mt_seed_with(sample_seed(F.seed, p, (uint32_t)(s0 + s)), x397[slot]);
+                ps.tab = ps.rnd;
+                float ox = rng_float(ps.rnd), oy = rng_float(ps.rnd);           // gi: always jittered (main.cpp:351-353)
+                double fx = (double)((float)x + ox), fy = (double)((float)y + oy);
+                const int which = stereo ? 1 : 0;
+                if (C.dof) dof_ray(C, fx, fy, ps.tab, ps.o, ps.d, which); else screen_ray(C, fx, fy, ps.o, ps.d, which);
+                if (stereo) {                                                   // the right eye's ray, drawn before any tracing
+                    V3 ro, rd;
+                    if (C.dof) dof_ray(C, fx, fy, ps.tab, ro, rd, 2); else screen_ray(C, fx, fy, ro, rd, 2);
+                    SB.r[0][slot] = ro.x; SB.r[1][slot] = ro.y; SB.r[2][slot] = ro.z;
+                    SB.r[3][slot] = rd.x; SB.r[4][slot] = rd.y; SB.r[5][slot] = rd.z;
+                }
+            } else {
+                ps.rnd.j = SB.g[0][slot]; ps.rnd.a = SB.g[1][slot]; ps.rnd.b = SB.g[2][slot];
+                ps.tab.j = SB.g[3][slot]; ps.tab.a = SB.g[4][slot]; ps.tab.b = SB.g[5][slot];
+                ps.o = v3(SB.r[0][slot], SB.r[1][slot], SB.r[2][slot]);
+                ps.d = v3(SB.r[3][slot], SB.r[4][slot], SB.r[5][slot]);
+            }
             ps.pm = c3(1, 1, 1);
             ps.slot = slot;
             ps.depth = 0;
@@ -352,12 +380,11 @@ __global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFrame F, 
         sampleRad[q] = 0; sampleRad[q + 1] = 0; sampleRad[q + 2] = 0;
     }
     if (ST & 1) flush_stats(st, c);
-    if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
 
 template <int ST>
 __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, PathQueue Qin, PathQueue Qout, ShadowQueue SQ, const QMeta* __restrict__ metaIn,
-                                                   QMeta* metaOut, QMeta* metaShadow, float* __restrict__ sampleRad, DStats* st)
+                                                   QMeta* metaOut, QMeta* metaShadow, float* __restrict__ sampleRad, StereoBuf SB, DStats* st)
 {
     __shared__ uint32_t sOff[FRAY_MAXSEG + 1];
     Cnt c = zero_cnt();
@@ -390,9 +417,9 @@ __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, 
             path_load_rest(Qin, i, ps);
             if (h.node <= -2) {                                       // main.cpp:201-208
                 C3 add = (ps.flags & RF_DIFFUSE) ? c3(0, 0, 0) : light_color(S.lights[-2 - h.node]) * ps.pm;
-                path_finish(sampleRad, st, ps, add);
+                path_finish(sampleRad, st, ps, add, SB);
             } else if (h.node < 0) {                                  // main.cpp:210-215
-                path_finish(sampleRad, st, ps, environment<ST>(S, ps.d, c) * ps.pm);
+                path_finish(sampleRad, st, ps, environment<ST>(S, ps.d, c) * ps.pm, SB);
             } else {
                 const FRAY_RO DNode& N = S.nodes[h.node];
                 const FRAY_RO DShader& sh = S.shaders[N.shader];
@@ -407,14 +434,14 @@ __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, 
                 float pdf;
                 spawn_ray(sh, info, win, ps.tab, wout, brdf, pdf);
                 if (pdf == -1.0f) {
-                    path_finish(sampleRad, st, ps, c3(1, 0, 0));
+                    path_finish(sampleRad, st, ps, c3(1, 0, 0), SB);
                 } else if (pdf == 0.0f) {
-                    path_finish(sampleRad, st, ps, c3(0, 0, 0));
+                    path_finish(sampleRad, st, ps, c3(0, 0, 0), SB);
                 } else {
                     ps.pm = ps.pm * brdf / pdf;
                     ps.o = wout.o; ps.d = wout.d; ps.depth = wout.depth; ps.flags = wout.flags;
                     // entry test of the next pathtrace() call (main.cpp:173-176)
-                    if (ps.depth > S.maxTraceDepth || intensity(ps.pm) < 0.01) path_finish(sampleRad, st, ps, c3(0, 0, 0));
+                    if (ps.depth > S.maxTraceDepth || intensity(ps.pm) < 0.01) path_finish(sampleRad, st, ps, c3(0, 0, 0), SB);
                     else cont = true;
                 }
             }
@@ -466,7 +493,8 @@ __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(DScene S, 
 
 // vfb[y][x] = (sum over samples in order) / spp  (main.cpp:348-360).  `sum` carries the running
 // FP32 sum across batches so the addition order is the reference's.
-__global__ __launch_bounds__(256) void k_pt_resolve(DFrame F, int nItems, int s0, int chunk, const float* __restrict__ sampleRad,
+__global__ __launch_bounds__(256) void k_pt_resolve(DFrame F, DCamera C, float saturation, int nItems, int s0, int chunk,
+                                                    const float* __restrict__ sampleRad, const float* __restrict__ sampleRadR,
                                                     float* __restrict__ sum, float* __restrict__ rgb)
 {
     for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < nItems; item += gridDim.x * blockDim.x) {
@@ -476,7 +504,17 @@ __global__ __launch_bounds__(256) void k_pt_resolve(DFrame F, int nItems, int s0
         C3 a = s0 == 0 ? c3(0, 0, 0) : c3(sum[si], sum[si + 1], sum[si + 2]);
         for (int s = 0; s < chunk; s++) {
             size_t q = ((size_t)s * nItems + item) * 3;
-            a = a + c3(sampleRad[q], sampleRad[q + 1], sampleRad[q + 2]);
+            C3 cl = c3(sampleRad[q], sampleRad[q + 1], sampleRad[q + 2]);
+            if (sampleRadR) {                                 // anaglyph blend, main.cpp:306-317
+                C3 cr = c3(sampleRadR[q], sampleRadR[q + 1], sampleRadR[q + 2]);
+                if (saturation != 1) {                        // Color::adjustSaturation, color.h:127-133
+                    float ml = (cl.r + cl.g + cl.b) / 3.0f, mr = (cr.r + cr.g + cr.b) / 3.0f;
+                    cl = c3(ml + (cl.r - ml) * saturation, ml + (cl.g - ml) * saturation, ml + (cl.b - ml) * saturation);
+                    cr = c3(mr + (cr.r - mr) * saturation, mr + (cr.g - mr) * saturation, mr + (cr.b - mr) * saturation);
+                }
+                cl = cl * ldc(C.leftMask) + cr * ldc(C.rightMask);
+            }
+            a = a + cl;
         }
         if (s0 + chunk >= F.spp) {
             a = a / (float)F.spp;

@@ -229,6 +229,8 @@ def main():
                 f_kb = tr["FETCH_SIZE"]["total"] / tr["FETCH_SIZE"]["launches"]
                 w_kb = tr["WRITE_SIZE"]["total"] / tr["WRITE_SIZE"]["launches"]
                 out["roofline"]["traffic"] = (f_kb + w_kb) * 1024.0
+                out["roofline"]["traffic_gb_per_s"] = (f_kb + w_kb) * 1024.0 / (avg_launch_ms * 1e-3) / 1e9
+                out["roofline"]["traffic_frac_of_hbm_peak"] = out["roofline"]["traffic_gb_per_s"] / 8000.0
                 out["roofline"]["traffic_note"] = ("rocprofv3 --pmc, per launch: FETCH_SIZE %.3g KB (raw; gfx950 may under-count wide reads by up to 2x) + "
                                                    "WRITE_SIZE %.3g KB" % (f_kb, w_kb))
             except (KeyError, ValueError, ZeroDivisionError):

@@ -542,11 +542,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * cn + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
                 for (int eye = 0; eye < (stereo ? 2 : 1); eye++) {
                     // queue 0 is dense: one segment holding every slot of the batch
-                    QMeta head{};
-                    head.n = (uint32_t)((size_t)nItems * cn); head.chunk = head.n; head.nSeg = 1;
-                    HIP_TRY(hipMemcpyAsync(sc->d_qmeta, &head, 16, hipMemcpyHostToDevice, stream));
-                    const uint32_t offs[2] = {0u, head.n};
-                    HIP_TRY(hipMemcpyAsync((unsigned char*)sc->d_qmeta + offsetof(QMeta, off), offs, sizeof offs, hipMemcpyHostToDevice, stream));
+                    hipLaunchKernelGGL(k_meta_dense, dim3(1), dim3(64), 0, stream, sc->d_qmeta, (uint32_t)((size_t)nItems * cn));
                     float* rad = eye == 0 ? sampleRad : sampleRadR;
                     // left pass of a stereo frame saves generator cursors at path end; mono and the right pass do not
                     const StereoBuf& save = (stereo && eye == 0) ? SB : SBnone;

@@ -299,6 +299,12 @@ __global__ __launch_bounds__(1024) void k_scan(QMeta* m0, QMeta* m1)
     if (threadIdx.x == 1023) { m->off[nSeg] = part[1023]; m->n = part[1023]; }
 }
 
+// Queue 0 of a batch is dense: a single segment that holds every slot.
+__global__ void k_meta_dense(QMeta* m, uint32_t n)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) { m->n = n; m->chunk = n; m->nSeg = 1; m->pad = 0; m->off[0] = 0; m->off[1] = n; }
+}
+
 // Dense index -> storage index of a segmented queue (sOff = offsets in LDS).
 FD uint32_t seg_lookup(const uint32_t* sOff, uint32_t nSeg, uint32_t chunk, uint32_t i)
 {

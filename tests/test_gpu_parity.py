@@ -476,3 +476,25 @@ def test_full_size_frames_of_the_other_configs(fray, abi, oracle, gpu, scene, W,
     d = (a[mask].astype(np.float64) - ref[mask]) ** 2
     assert np.all(np.sqrt(d.mean(axis=0)) <= RMS_TOL), np.sqrt(d.mean(axis=0))
     s.close()
+
+
+def test_render_device_into_torch_tensor_on_a_side_stream(fray, abi, gpu):
+    """frayhip_render_device: caller-owned device memory + a caller stream (what bench.py uses)."""
+    import torch
+    s = open_scene(fray, "cornell_box.fray", 96, 64, numPaths=5)
+    s.beginRender()
+    host, st0 = s.render(seed=42)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        frame = torch.full((64, 96, 3), -1.0, dtype=torch.float32, device="cuda")
+        st = s.render_device(frame.data_ptr(), seed=42, stream=side.cuda_stream)
+    side.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), host)
+    assert st["trace_launches"] == st0["trace_launches"] > 0 and st["ms_trace"] > 0
+    # hit records into device tensors as well
+    ids = torch.zeros((64, 96), dtype=torch.int32, device="cuda")
+    dist = torch.zeros((64, 96), dtype=torch.float64, device="cuda")
+    s.render_device(None, mode=abi.MODE_PRIMARY_ID, d_id_ptr=ids.data_ptr(), d_dist_ptr=dist.data_ptr(), stream=side.cuda_stream)
+    hi, hd, _ = s.primary_hits()
+    assert np.array_equal(ids.cpu().numpy(), hi) and np.array_equal(dist.cpu().numpy(), hd)
+    s.close()

@@ -40,6 +40,21 @@ def open_scene(fray_amd, name, W, H, over):
     return s
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask, capped by a cgroup CPU quota if there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0):
     """The oracle (a scalar C++ port of the reference path) timed on this box's host cores on a
     bounded sample of the same workload: every `stride`-th 48x48 bucket of the same frame."""
@@ -47,8 +62,7 @@ def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0):
     orc = Oracle(abi)
     name, W, H, over, _ = wl
     s = open_scene(fray_amd, name, W, H, over)
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    threads = min(usable_cores(), 64)
     nb = ((W - 1) // 48 + 1) * ((H - 1) // 48 + 1)
     # calibrate on `threads` buckets spread over the frame, then size the sample for ~target_seconds
     mode = abi.MODE_RENDER
@@ -64,10 +78,17 @@ def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0):
     dt = time.time() - t0
     rays = st["closest_rays"] + st["shadow_rays"]
     n_b = len(range(0, nb, stride))
+    # single-thread figure on a smaller sample (~4 s)
+    stride1 = max(1, int(nb / max(1.0, 4.0 / (per_bucket * threads))))
+    t0 = time.time()
+    _, st1 = orc.render(s.desc, mode, seed=seed, bucket_first=0, bucket_stride=stride1, threads=1)
+    dt1 = max(time.time() - t0, 1e-6)
     s.close()
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": "%d of %d buckets (every %d-th 48x48 bucket) of the same frame, all spp, %.1f s, %d threads" % (n_b, nb, stride, dt, threads),
-            "frame_ms_extrapolated": dt * 1e3 * nb / n_b}
+            "frame_ms_extrapolated": dt * 1e3 * nb / n_b,
+            "one_thread_mrays_per_s": (st1["closest_rays"] + st1["shadow_rays"]) / dt1 / 1e6,
+            "one_thread_sample": "%d buckets, %.1f s" % (len(range(0, nb, stride1)), dt1)}
 
 
 def main():

@@ -379,6 +379,15 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     return FRAYHIP_OK;
 }
 
+int frayhip_scene_set_view(frayhip_scene* s, const frayhip_camera* camera, const frayhip_settings* settings)
+{
+    if (!s) { set_error("frayhip_scene_set_view: null scene"); return FRAYHIP_E_ARG; }
+    if (settings && (settings->frameWidth <= 0 || settings->frameHeight <= 0)) { set_error("frayhip_scene_set_view: bad frame size"); return FRAYHIP_E_ARG; }
+    if (camera) s->camera = *camera;
+    if (settings) s->settings = *settings;
+    return FRAYHIP_OK;
+}
+
 void frayhip_scene_destroy(frayhip_scene* s)
 {
     if (!s) return;

@@ -98,6 +98,13 @@ class Scene:
         _check(lib.frayhip_scene_create(C.byref(self.desc), C.byref(self._dev)))
         return self
 
+    def beginFrame(self):
+        """Pushes the current settings / camera records to the uploaded scene (Scene::beginFrame: the
+        reference re-derives the camera every frame, so callers may move it between render() calls)."""
+        self._need_dev()
+        _check(lib.frayhip_scene_set_view(self._dev, C.byref(self.desc.camera), C.byref(self.desc.settings)))
+        return self
+
     def endRender(self):
         if self._dev:
             lib.frayhip_scene_destroy(self._dev)

@@ -257,6 +257,10 @@ int  frayhip_init(int device_id);
 /* Deep-copies the description into device memory. */
 int  frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out);
 void frayhip_scene_destroy(frayhip_scene* s);
+/* Replaces the camera and the global settings of an uploaded scene without touching the geometry
+ * (the reference's interactive loop mutates scene.camera between frames, main.cpp:437-491;
+ * Camera::beginFrame re-derives everything per frame anyway).  Either pointer may be NULL. */
+int  frayhip_scene_set_view(frayhip_scene* s, const frayhip_camera* camera, const frayhip_settings* settings);
 
 /* Blocking render.  Any output pointer may be NULL.  Host buffers, row-major:
  *   rgb      W*H*3 float  -- `vfb` (main.cpp:53,360), linear, unclamped

@@ -498,3 +498,18 @@ def test_render_device_into_torch_tensor_on_a_side_stream(fray, abi, gpu):
     hi, hd, _ = s.primary_hits()
     assert np.array_equal(ids.cpu().numpy(), hi) and np.array_equal(dist.cpu().numpy(), hd)
     s.close()
+
+
+def test_camera_and_settings_can_change_between_frames(fray, abi, oracle, gpu):
+    s = open_scene(fray, "boxed.fray", 80, 60, wantAA=0)
+    s.beginRender()
+    a, _, _ = s.primary_hits()
+    s.camera.yaw += 25.0
+    s.camera.pos[1] += 3.0
+    s.settings.frameWidth, s.settings.frameHeight = 64, 64
+    s.beginFrame()
+    b, bd, _ = s.primary_hits()
+    oi, od, _ = oracle.render(s.desc, abi.MODE_PRIMARY_ID)
+    assert b.shape == (64, 64) and np.array_equal(b, oi) and np.array_equal(bd, od)
+    assert a.shape == (60, 80)
+    s.close()

@@ -16,7 +16,7 @@ HIP_SRC  := fray_amd/csrc/capi.hip
 HIP_OBJ  := $(HIP_SRC:.hip=.o)
 HIP_HDR  := $(wildcard fray_amd/csrc/*.h) $(wildcard fray_amd/csrc/*.hpp) include/frayhip.h
 
-all: fray_amd/libfrayhip.so oracle/libfray_oracle.so ref
+all: fray_amd/libfrayhip.so oracle/libfray_oracle.so examples/fray_render ref
 
 fray_amd/csrc/%.o: fray_amd/csrc/%.cpp $(HIP_HDR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
@@ -30,12 +30,16 @@ fray_amd/libfrayhip.so: $(HOST_OBJ) $(HIP_OBJ)
 oracle/libfray_oracle.so: oracle/fray_oracle.cpp include/frayhip.h
 	$(CXX) $(CXXFLAGS) -shared -pthread -o $@ $<
 
+# C++ host example over the C ABI (no Python, no torch)
+examples/fray_render: examples/fray_render.cpp include/frayhip.h fray_amd/libfrayhip.so
+	$(CXX) -O2 -std=c++17 -Iinclude $< -o $@ -Lfray_amd -lfrayhip -Wl,-rpath,'$$ORIGIN/../fray_amd' -Wl,-rpath,/opt/rocm/lib
+
 # Partial reference build: only when the reference tree is mounted (never on the GPU box).
 ref:
 	@if [ -d /root/reference/src ]; then $(MAKE) -C oracle -f Makefile.ref; else echo "reference tree absent: oracle/_ref not rebuilt"; fi
 
 clean:
-	rm -f fray_amd/csrc/*.o fray_amd/libfrayhip.so oracle/libfray_oracle.so
+	rm -f fray_amd/csrc/*.o fray_amd/libfrayhip.so oracle/libfray_oracle.so examples/fray_render
 	rm -rf oracle/_ref
 
 .PHONY: all ref clean

@@ -513,3 +513,23 @@ def test_camera_and_settings_can_change_between_frames(fray, abi, oracle, gpu):
     assert b.shape == (64, 64) and np.array_equal(b, oi) and np.array_equal(bd, od)
     assert a.shape == (60, 80)
     s.close()
+
+
+def test_cxx_host_example_renders_like_the_python_path(fray, gpu, tmp_path):
+    """examples/fray_render: a C++ main() over the C ABI (no Python, no torch in that process)."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "fray_render")
+    if not os.path.exists(exe):
+        pytest.fail("examples/fray_render is not built (make)")
+    out = tmp_path / "c.bmp"
+    r = subprocess.run([exe, os.path.join(ROOT, "scenes", "cornell_box.fray"), str(out), "64", "48", "4"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Render took" in r.stdout and "Exited cleanly" in r.stdout
+    s = open_scene(fray, "cornell_box.fray", 64, 48, numPaths=4)
+    s.beginRender()
+    img, _ = s.render(seed=42)
+    ref = tmp_path / "p.bmp"
+    assert fray.lib.frayhip_save_bmp(str(ref).encode(), img.ctypes.data, 64, 48) == 0
+    assert open(out, "rb").read() == open(ref, "rb").read()
+    s.close()

@@ -317,7 +317,7 @@ void decode(const std::vector<unsigned char>& file, Image& img)
     if (compression != 0 && compression != 4) throw ExrError("only NONE and PIZ compression are supported");
     if (lineOrder > 1) throw ExrError("unsupported line order");
     const int W = x1 - x0 + 1, H = y1 - y0 + 1;
-    if (W > 16384 || H > 16384) throw ExrError("image too large");
+    if (W > 8192 || H > 8192) throw ExrError("image too large");
     const int lines = compression == 4 ? 32 : 1;
     const int nChunks = (H + lines - 1) / lines;
     std::vector<uint64_t> offsets(nChunks);

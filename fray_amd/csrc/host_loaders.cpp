@@ -248,6 +248,17 @@ bool load_obj(const char* path, MeshData& mesh)
     }
     fclose(f);
     if (mesh.normals.size() == 3) mesh.normals.clear();
+    // Indices the file does not back (beyond the arrays, or negative) read the dummy element 0; the
+    // reference would index out of bounds there.
+    {
+        const int nv = (int)(mesh.vertices.size() / 3), nn = (int)(mesh.normals.size() / 3), nt = (int)(mesh.uvs.size() / 3);
+        for (auto& t : mesh.triangles)
+            for (int k = 0; k < 3; k++) {
+                if (t.v[k] < 0 || t.v[k] >= nv) t.v[k] = 0;
+                if (t.n[k] < 0 || t.n[k] >= nn) t.n[k] = 0;
+                if (t.t[k] < 0 || t.t[k] >= nt) t.t[k] = 0;
+            }
+    }
 
     const bool haveUV = !mesh.uvs.empty(), haveN = !mesh.normals.empty();
     for (auto& t : mesh.triangles) {
@@ -317,7 +328,15 @@ bool load_bmp(const char* path, Image& img, std::string& err)
     int colors = i32(46);
     if (!(bpp == 8 || bpp == 24 || bpp == 32)) { err = "unsupported bpp"; return false; }
     if (planes != 1) { err = "multichannel bmp"; return false; }
-    if (w <= 0 || h <= 0) { err = "bad dimensions"; return false; }
+    if (w <= 0 || h <= 0 || w > 32768 || h > 32768) { err = "bad dimensions"; return false; }
+    {   // a truncated or corrupt file must not drive a huge allocation
+        long here = ftell(fp);
+        fseek(fp, 0, SEEK_END);
+        long size = ftell(fp);
+        fseek(fp, here, SEEK_SET);
+        long rowBytes = ((long)w * (bpp / 8) + 3) / 4 * 4;
+        if (imgOffset < 54 || imgOffset > size || rowBytes > (size - imgOffset) + 4) { err = "file is shorter than its header claims"; return false; }
+    }
     float palette[256][3];
     int toread = 0;
     if (bpp <= 8) {

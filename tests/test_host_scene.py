@@ -250,3 +250,26 @@ def test_exr_piz_cubemap_decodes(fray, oracle):
     means = [float(tex[e.texel_offset[f]:e.texel_offset[f] + 256 * 256 * 3].mean()) for f in range(6)]
     assert max(range(6), key=lambda f: means[f]) == 4 and min(range(6), key=lambda f: means[f]) == 1   # POSY / NEGY
     s.close()
+
+
+def test_malformed_assets_fail_cleanly_or_fall_back_to_the_dummy_element(fray, tmp_path):
+    # OBJ indices that nothing backs read the dummy element 0 (the reference would index out of bounds)
+    obj = "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\nf 1 2 99\nf -4 2 3\nf 1/7/9 2 3\n"
+    s = parse(fray, tmp_path, BASE + 'Mesh m {\n\tfile "m.obj"\n}\n', {"m.obj": obj})
+    m = s.desc.meshes[0]
+    assert [list(m.triangles[i].v) for i in range(4)] == [[1, 2, 3], [1, 2, 0], [0, 2, 3], [1, 2, 3]]
+    assert list(m.triangles[3].t) == [0, 0, 0] and list(m.triangles[3].n) == [0, 0, 0]
+    # a BMP whose header promises more pixels than the file holds is rejected, not allocated
+    good = bmp24(4, 4, lambda x, y: (x * 60, y * 60, 0))
+    lying = bytearray(good)
+    lying[18:22] = struct.pack("<i", 30000)
+    lying[22:26] = struct.pack("<i", 30000)
+    for data in (bytes(lying), good[:40], b"XX" + good[2:]):
+        with pytest.raises(fray.FrayError):
+            parse(fray, tmp_path, BASE + 'BitmapTexture t {\n\tfile "t.bmp"\n}\n', {"t.bmp": data})
+    # a corrupt cubemap face leaves the environment declared but not loaded (no crash, misses are black)
+    exr = bytearray(open(os.path.join(os.path.dirname(__file__), "..", "scenes", "env", "forest", "posx.exr"), "rb").read())
+    exr[5000:5100] = bytes(100)
+    files = {"env/%s.exr" % f: bytes(exr) for f in ("negx", "negy", "negz", "posx", "posy", "posz")}
+    s = parse(fray, tmp_path, BASE + 'CubemapEnvironment e {\n\tfolder "env"\n}\n', files)
+    assert s.desc.environment.present == 1 and s.desc.environment.loaded == 0

@@ -24,6 +24,9 @@ WORKLOADS = {
                      "cornell_box.fray 1920x1080 64spp path trace, maxTraceDepth 6 (BASELINE configs[2])"),
     "smallpt_pt64": ("smallpt.fray", 1920, 1080, dict(gi=1, numPaths=64), "smallpt.fray 1920x1080 64spp path trace"),
     "boxed_whitted": ("boxed.fray", 1920, 1080, dict(wantAA=0), "boxed.fray 1920x1080 1spp Whitted (KD meshes, 32 shadow rays/hit)"),
+    "forest_dof256": ("forest.fray", 1920, 1080, dict(wantAA=0, dof=1, numDOFSamples=256, interactive=0),
+                      "forest.fray 1920x1080 DOF 256spp Whitted (BASELINE configs[3] on one GPU)"),
+    "zaphod_whitted": ("zaphod.fray", 1920, 1080, dict(wantAA=0, dof=0), "zaphod.fray 1920x1080 1spp Whitted (BASELINE configs[1])"),
     "forest_dof16": ("forest.fray", 1920, 1080, dict(wantAA=0, dof=1, numDOFSamples=16, interactive=0), "forest.fray 1920x1080 DOF 16spp Whitted"),
     "dragon_primary": ("hw9/dragon.fray", 1920, 1080, dict(wantAA=0), "hw9/dragon.fray 1920x1080 primary rays (100k-triangle KD)"),
 }

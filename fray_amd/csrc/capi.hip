@@ -320,6 +320,8 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         putX(o.T, l.T);
         put3(o.center, l.center);
         o.area = l.area;
+        o.areaXsize = 1.0 / l.xSubd;
+        o.areaYsize = 1.0 / l.ySubd;
     }
     size_t oLights = A.add(lights.data(), lights.size() * sizeof(DLight));
     size_t oMeshes = A.add(nullptr, 0);              // reserve aligned slots for the tables that hold device pointers
@@ -366,6 +368,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     }
     S.nNodes = d.n_nodes;
     S.nLights = d.n_lights;
+    S.probPickLight = d.n_lights > 0 ? 1.0f / (float)d.n_lights : 0.0f;
     sc->camera = d.camera;
     sc->settings = d.settings;
     // [0] everything but k_pt_shadow, [1] k_pt_shadow

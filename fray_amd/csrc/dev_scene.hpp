@@ -96,6 +96,7 @@ struct DLight {
     DXform T;
     double center[3];
     double area;
+    double areaXsize, areaYsize;   // 1.0 / xSubd, 1.0 / ySubd (RectLight::getNthSample, lights.cpp:54-55), divided once on the host
 };
 
 struct DEnv {
@@ -126,6 +127,7 @@ struct DScene {
     const FRAY_RO DLight* lights;
     DEnv env;
     int32_t nNodes, nLights;
+    float probPickLight;           // 1.0f / lights.size() (main.cpp:160)
     float ambient[3];
     int32_t maxTraceDepth, gi;
     float saturation;

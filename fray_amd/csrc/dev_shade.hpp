@@ -197,8 +197,8 @@ FD void light_nth_sample(const FRAY_RO DLight& L, int idx, V3 shadePos, G& tab, 
     }
     int column = idx % L.xSubd;
     int row = idx / L.xSubd;
-    double areaXsize = 1.0 / L.xSubd;
-    double areaYsize = 1.0 / L.ySubd;
+    double areaXsize = L.areaXsize;
+    double areaYsize = L.areaYsize;
     double areaXstart = column * areaXsize;
     double areaYstart = row * areaYsize;
     double p_x = areaXstart + areaXsize * rng_float(tab);
@@ -360,7 +360,7 @@ FD bool nee_prepare(const DScene& S, V3 rayDir, const HitInfo& info, C3 pm, cons
     C3 brdfAtPoint = brdf_eval(sh, info, w_out);
     if (intensity(brdfAtPoint) == 0) { contrib = c3(0, 0, 0); return true; }
     float probHitLightArea = (float)(1.0f / solidAngle);
-    float probPickThisLight = 1.0f / (float)S.nLights;
+    float probPickThisLight = S.probPickLight;
     float chooseLightProb = probHitLightArea * probPickThisLight;
     contrib = Le * pm * brdfAtPoint / chooseLightProb;
     return true;

@@ -524,6 +524,8 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             if (set.maxTraceDepth > 60) { set_error("frayhip_render: maxTraceDepth above 60 is not supported"); return FRAYHIP_E_UNSUPPORTED; }
             int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, ((size_t)1 << 26) / (size_t)nItems);
             if (chunk > spp) chunk = spp;
+            while (chunk > 1 && (size_t)nItems * chunk > ((size_t)1 << 30)) chunk /= 2;   // slots are 32-bit
+            if ((size_t)nItems > ((size_t)1 << 30)) { set_error("frayhip_render: frame too large for one call (more than 2^30 pixels per rank)"); return FRAYHIP_E_UNSUPPORTED; }
             const size_t nPaths = (size_t)nItems * chunk;
             // per-wave segments round their share up to a multiple of 64: one extra wave-load per wave of the grid
             const size_t nQueue = nPaths + (size_t)grid_for(nPaths) * 4 * 128;

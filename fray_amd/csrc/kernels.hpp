@@ -26,7 +26,21 @@
 #endif
 
 // ---- work item -> pixel ------------------------------------------------------------------------
+// Inside a 48x48 bucket the items run over 8x8 pixel tiles (6x6 of them), so the 64 lanes of a wave
+// hold a square of neighbouring pixels: their camera rays walk the same part of a KD-tree.  Every
+// (pixel, sample) is independent, so the order has no effect on the picture.
 FD bool item_pixel(const DFrame& F, int item, int& x, int& y)
+{
+    int k = item / 2304, local = item - k * 2304;
+    int b = F.bucketFirst + k * F.bucketStride;
+    int bx = b % F.BW, by = b / F.BW;
+    int tile = local >> 6, in = local & 63;
+    x = bx * 48 + (tile % 6) * 8 + (in & 7);
+    y = by * 48 + (tile / 6) * 8 + (in >> 3);
+    return x < F.W && y < F.H;
+}
+// the packed (gather) layout: bucket-major, rows of 48 pixels inside a bucket (include/frayhip.h)
+FD bool packed_pixel(const DFrame& F, int item, int& x, int& y)
 {
     int k = item / 2304, local = item - k * 2304;
     int b = F.bucketFirst + k * F.bucketStride;
@@ -537,7 +551,7 @@ __global__ __launch_bounds__(256) void k_pack(DFrame F, int nItems, int channels
 {
     for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < nItems; item += gridDim.x * blockDim.x) {
         int x, y;
-        bool ok = item_pixel(F, item, x, y);
+        bool ok = packed_pixel(F, item, x, y);
         for (int ch = 0; ch < channels; ch++) {
             size_t a = ((size_t)y * F.W + x) * channels + ch, b = (size_t)item * channels + ch;
             if (unpack) { if (ok) frame[a] = packed[b]; }

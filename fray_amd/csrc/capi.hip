@@ -129,6 +129,27 @@ bool shader_uses_uv(const frayhip_scene_desc& d, int s, int depth = 0)
     return false;
 }
 
+// Grid of a persistent kernel (k_primary, k_whitted: waves claim work from DStats.cursor): exactly the
+// blocks that are resident at once -- a 256-thread block is one wave per SIMD, so `wavesPerSimd`
+// blocks per compute unit.
+// d_stats: two DStats blocks, then (256-byte aligned) the work cursors; one memset clears all of it per frame
+constexpr size_t kCursorOffset = (2 * sizeof(DStats) + 255) / 256 * 256;
+constexpr size_t kStatsBytes = kCursorOffset + sizeof(DCursors);
+
+int persistent_grid(size_t n, int wavesPerSimd)
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else cus = 256;
+    }
+    size_t blocks = (n + 255) / 256, cap = (size_t)cus * wavesPerSimd;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
 int grid_for(size_t n)
 {
     size_t blocks = (n + 255) / 256;
@@ -372,7 +393,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     sc->camera = d.camera;
     sc->settings = d.settings;
     // [0] everything but k_pt_shadow, [1] k_pt_shadow
-    if (hipMalloc((void**)&sc->d_stats, 2 * sizeof(DStats)) != hipSuccess || hipMalloc((void**)&sc->d_qmeta, 3 * sizeof(QMeta)) != hipSuccess ||
+    if (hipMalloc((void**)&sc->d_stats, kStatsBytes) != hipSuccess || hipMalloc((void**)&sc->d_qmeta, 3 * sizeof(QMeta)) != hipSuccess ||
         hipEventCreate(&sc->evA) != hipSuccess || hipEventCreate(&sc->evB) != hipSuccess) {
         set_error("frayhip_scene_create: could not allocate the per-scene device state");
         frayhip_scene_destroy(sc);
@@ -486,7 +507,8 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     S.saturation = set.saturation;
     DCamera C = camera_begin_frame(sc->camera, W, H);
 
-    HIP_TRY(hipMemsetAsync(sc->d_stats, 0, 2 * sizeof(DStats), stream));
+    HIP_TRY(hipMemsetAsync(sc->d_stats, 0, kStatsBytes, stream));
+    DCursors* cursors = (DCursors*)((unsigned char*)sc->d_stats + kCursorOffset);
     HIP_TRY(hipEventRecord(sc->evA, stream));
     size_t nTraceEvents = 0, nShadowEvents = 0;
 
@@ -494,7 +516,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
         if (nItems > 0) {
             hipEvent_t a = pool_event(sc, 0), b = pool_event(sc, 1);
             HIP_TRY(hipEventRecord(a, stream));
-            hipLaunchKernelGGL(k_primary<ST>, dim3(grid_for(nItems)), dim3(256), 0, stream, S, C, F, nItems, d_id, d_dist, sc->d_stats);
+            hipLaunchKernelGGL(k_primary<ST>, dim3(persistent_grid(nItems, FRAY_PRIMARY_WAVES)), dim3(256), 0, stream, S, C, F, nItems, d_id, d_dist, sc->d_stats, cursors);
             HIP_TRY(hipEventRecord(b, stream));
             nTraceEvents = 2;
         }
@@ -505,7 +527,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             if (nItems > 0) {
                 // workspace: per-thread mt19937 state columns for samples that draw more than 227 words,
                 // then x[397] of every (pixel, sample) seed
-                const int grid = grid_for(nItems);
+                const int grid = persistent_grid(nItems, FRAY_WHITTED_WAVES);
                 const size_t colBytes = ((size_t)grid * 256 * 624 * sizeof(uint32_t) + 255) / 256 * 256;
                 int rc = ensure_work(sc, colBytes + (size_t)nItems * spp * sizeof(uint32_t));
                 if (rc) return rc;
@@ -514,9 +536,9 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 hipEvent_t a = pool_event(sc, 0), b = pool_event(sc, 1);
                 HIP_TRY(hipEventRecord(a, stream));
                 if (sc->whittedNeedsRecursion)
-                    hipLaunchKernelGGL((k_whitted<ST, true>), dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats);
+                    hipLaunchKernelGGL((k_whitted<ST, true>), dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats, cursors);
                 else
-                    hipLaunchKernelGGL((k_whitted<ST, false>), dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats);
+                    hipLaunchKernelGGL((k_whitted<ST, false>), dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats, cursors);
                 HIP_TRY(hipEventRecord(b, stream));
                 nTraceEvents = 2;
             }

@@ -146,3 +146,5 @@ struct DFrame {
 struct DStats {
     unsigned long long closest, shadow, node, kdInner, leafRefs, tri, prim, smooth, samples, tex, rngOverflow;   // rngOverflow: any "left the supported envelope" event
 };
+// Work cursors of the persistent kernels (kernels.hpp claim_items): one per cache line.
+struct DCursors { unsigned int v[8][32]; };

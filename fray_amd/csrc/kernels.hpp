@@ -50,6 +50,30 @@ FD bool packed_pixel(const DFrame& F, int item, int& x, int& y)
     return x < F.W && y < F.H;
 }
 
+// Persistent waves.  The work items of a frame form nItems / 64 tiles (one 8x8 pixel tile = one wave's
+// worth; nItems is a multiple of 2304, hence of 64), split into 8 contiguous ranges with one cursor
+// each (DCursors: one 128-byte line per cursor, zeroed by the host with the counters).  A wave claims
+// one tile at a time, first from the range of its block's XCD (blocks go round-robin over the 8
+// XCDs, so an XCD's L2 sees one part of the picture and of the KD-trees), then from the others in
+// turn.  One cursor for the whole frame would serialise ~30 k atomics on one address (~6 ns each),
+// which a 0.25 ms frame notices; eight run in parallel.  `r` counts the ranges this wave has seen
+// exhausted (start at 0); after the eighth the wave leaves, so the grid always drains.
+FD int claim_items(DCursors* cur, int nItems, int& r)
+{
+    const int nTiles = nItems >> 6, per = (nTiles + 7) >> 3;
+    const int home = (int)(blockIdx.x & 7);
+    while (r < 8) {
+        const int range = (home + r) & 7;
+        unsigned int t = 0;
+        if ((threadIdx.x & 63) == 0) t = atomicAdd(&cur->v[range][0], 1u);
+        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+        const int tile = range * per + (int)t;
+        if (t < (unsigned int)per && tile < nTiles) return tile * 64 + (int)(threadIdx.x & 63);
+        r++;
+    }
+    return nItems;
+}
+
 FD void flush_stats(DStats* st, const Cnt& c)
 {
     atomicAdd(&st->closest, c.closest); atomicAdd(&st->shadow, c.shadow); atomicAdd(&st->node, c.node);
@@ -124,10 +148,10 @@ __global__ __launch_bounds__(256) void k_seed(DFrame F, int nItems, int s0, int 
 // ---- MODE_PRIMARY_ID ------------------------------------------------------------------------------
 template <int ST>
 __global__ __launch_bounds__(256, FRAY_PRIMARY_WAVES) void k_primary(DScene S, DCamera C, DFrame F, int nItems, int32_t* __restrict__ hitId,
-                                                 double* __restrict__ hitDist, DStats* st)
+                                                 double* __restrict__ hitDist, DStats* st, DCursors* cur)
 {
     Cnt c = zero_cnt();
-    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < nItems; item += gridDim.x * blockDim.x) {
+    for (int r = 0, item = claim_items(cur, nItems, r); item < nItems; item = claim_items(cur, nItems, r)) {
         int x, y;
         if (!item_pixel(F, item, x, y)) continue;
         V3 o, d;
@@ -163,13 +187,13 @@ __constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0, 0.6}, 
 
 template <int ST, bool REC>
 __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(DScene S, DCamera C, DFrame F, int nItems, float* __restrict__ rgb, uint32_t* mtWork,
-                                                 const uint32_t* __restrict__ x397, DStats* st)
+                                                 const uint32_t* __restrict__ x397, DStats* st, DCursors* cur)
 {
     Cnt c = zero_cnt();
     MtLong tab;
     tab.stride = gridDim.x * blockDim.x;
     tab.st = mtWork + (blockIdx.x * blockDim.x + threadIdx.x);
-    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < nItems; item += gridDim.x * blockDim.x) {
+    for (int r = 0, item = claim_items(cur, nItems, r); item < nItems; item = claim_items(cur, nItems, r)) {
         int x, y;
         if (!item_pixel(F, item, x, y)) continue;
         const uint32_t p = (uint32_t)y * (uint32_t)F.W + (uint32_t)x;

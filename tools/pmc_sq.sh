@@ -3,7 +3,8 @@
 # Each pass is its own rocprofv3 run with --kernel-trace only, as the pool requires.
 set -e
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/pmc_sq
+WL=${1:-cornell_pt64}
+OUT=$ROOT/gpurun_out/pmc_sq_$WL
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -13,7 +14,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_
            "GRBM_GUI_ACTIVE GRBM_COUNT TCC_HIT_sum TCC_MISS_sum" \
            "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_REQ_sum"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/p$i.log 2>&1 || echo "pass $i failed (see p$i.log)"
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload $WL > $OUT/p$i.log 2>&1 || echo "pass $i failed (see p$i.log)"
   echo "pass $i done" >> $OUT/progress.log
 done
 cd $ROOT

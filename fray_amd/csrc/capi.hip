@@ -150,6 +150,16 @@ int persistent_grid(size_t n, int wavesPerSimd)
     return (int)blocks;
 }
 
+#ifndef FRAY_BOUNCE_BLOCKS
+#define FRAY_BOUNCE_BLOCKS 2048
+#endif
+int bounce_grid(size_t n)
+{
+    size_t blocks = (n + 255) / 256;
+    if (blocks > FRAY_BOUNCE_BLOCKS) blocks = FRAY_BOUNCE_BLOCKS;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
 int grid_for(size_t n)
 {
     size_t blocks = (n + 255) / 256;
@@ -587,7 +597,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     for (int b = 0; b < nBounce; b++) {
                         hipEvent_t ea = pool_event(sc, nTraceEvents), eb = pool_event(sc, nTraceEvents + 1);
                         HIP_TRY(hipEventRecord(ea, stream));
-                        hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, Q[b & 1], Q[(b + 1) & 1], SQ,
+                        hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(bounce_grid((size_t)nItems * cn)), dim3(256), 0, stream, S, Q[b & 1], Q[(b + 1) & 1], SQ,
                                            sc->d_qmeta + (b & 1), sc->d_qmeta + ((b + 1) & 1), sc->d_qmeta + 2, rad, save, sc->d_stats);
                         HIP_TRY(hipEventRecord(eb, stream));
                         nTraceEvents += 2;

@@ -16,7 +16,7 @@
 #define FRAY_PRIMARY_WAVES 5
 #endif
 #ifndef FRAY_WHITTED_WAVES
-#define FRAY_WHITTED_WAVES 4   // measured on boxed / forest: 1 -> 47.8 / 112 ms, 2 -> 32.5 / 81, 3 -> 30.5 / 73, 4 -> 26.6 / 71.5
+#define FRAY_WHITTED_WAVES 3   // measured with persistent waves (boxed / forest DOF16 / zaphod ms): 2 -> 16.7 / 28.9 / 0.34, 3 -> 15.2 / 26.1 / 0.35, 4 -> 15.0 / 26.3 / 0.42, 5 -> 15.4 / 26.2 / 0.53
 #endif
 #ifndef FRAY_SHADOW_WAVES
 #define FRAY_SHADOW_WAVES 4

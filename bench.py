@@ -259,6 +259,18 @@ def main():
                                                    "WRITE_SIZE %.3g KB" % (f_kb, w_kb))
             except (KeyError, ValueError, ZeroDivisionError):
                 pass
+        # what actually bounds the kernel: FP64 VALU issue.  Static figures from the SQ
+        # counter passes of this same command (tools/pmc_sq.sh -> profiles/r01_f_sq_counters.json).
+        sq_path = os.path.join(ROOT, "profiles", "r01_f_sq_counters.json")
+        if world == 1 and args.workload == "cornell_pt64" and os.path.exists(sq_path):
+            try:
+                sq = json.load(open(sq_path))
+                out["roofline"]["valu"] = {k: {"valu_busy": sq[n]["derived"]["valu_busy"], "lane_utilisation": sq[n]["derived"]["lane_utilisation"]}
+                                           for k, n in (("k_pt_bounce", "void k_pt_bounce<0>"), ("k_pt_shadow", "void k_pt_shadow<0>"))}
+                out["roofline"]["valu"]["note"] = ("rocprofv3 --pmc SQ_ACTIVE_INST_VALU x4 / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs); "
+                                                   "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)")
+            except (KeyError, ValueError):
+                pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(fray_amd, abi, wl, args.seed) if mode == abi.MODE_RENDER else None
         print(json.dumps(out), flush=True)

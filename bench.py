@@ -28,6 +28,8 @@ WORKLOADS = {
                       "forest.fray 1920x1080 DOF 256spp Whitted (BASELINE configs[3] on one GPU)"),
     "zaphod_whitted": ("zaphod.fray", 1920, 1080, dict(wantAA=0, dof=0), "zaphod.fray 1920x1080 1spp Whitted (BASELINE configs[1])"),
     "forest_dof16": ("forest.fray", 1920, 1080, dict(wantAA=0, dof=1, numDOFSamples=16, interactive=0), "forest.fray 1920x1080 DOF 16spp Whitted"),
+    "smallpt_4k_pt1024": ("smallpt.fray", 4096, 4096, dict(gi=1, numPaths=1024),
+                          "smallpt.fray 4096x4096 1024spp path trace, maxTraceDepth 8 (BASELINE configs[4] on one GPU; use --steps 1 --warmup 0)"),
     "dragon_primary": ("hw9/dragon.fray", 1920, 1080, dict(wantAA=0), "hw9/dragon.fray 1920x1080 primary rays (100k-triangle KD)"),
 }
 
@@ -215,7 +217,9 @@ def main():
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         kern = {abi.MODE_PRIMARY_ID: "k_primary"}.get(mode, "k_pt_bounce" if scene.settings.gi else "k_whitted")
         out = {
-            "metric": "Mrays/s (closest-hit + shadow rays) at 1920x1080, 64spp path trace",
+            "metric": "Mrays/s (closest-hit + shadow rays) at %dx%d, %dspp %s" % (
+                W, H, scene.samples_per_pixel(),
+                "primary rays" if mode == abi.MODE_PRIMARY_ID else ("path trace" if scene.settings.gi else "Whitted")),
             "value": rays_total / (ms_per_step * 1e-3) / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

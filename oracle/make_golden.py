@@ -31,6 +31,9 @@ CASES = [
     ("smallpt_whitted", "smallpt.fray", 48, 36, "gi=0;wantAA=0", 5, 0),
     ("sphtri_pt", "hw12/sphtri.fray", 48, 36, "gi=1;numPaths=4", 5, 100),
     ("dragon_whitted", "hw9/dragon.fray", 48, 32, "wantAA=0", 3, 300),
+    ("bokeh_dof", "hw10/bokeh.fray", 48, 36, "wantAA=0;numDOFSamples=6", 3, 300),      # Cube - Cube CSG, Layered(Refl over textured Lambert), Phong, DOF
+    ("axe_whitted", "hw9/axe_test.fray", 48, 36, "wantAA=0", 3, 300),
+    ("nonconvex_aa", "hw9/nonconvex.fray", 48, 36, "wantAA=1", 3, 200),
 ]
 
 
@@ -82,5 +85,8 @@ if __name__ == "__main__":
         worker(a[0], a[1], int(a[2]), int(a[3]), a[4], int(a[5]), int(a[6]))
     else:
         os.makedirs(OUT, exist_ok=True)
+        only = os.environ.get("GOLDEN_ONLY", "").split(",") if os.environ.get("GOLDEN_ONLY") else None
         for c in CASES:
+            if only and c[0] not in only:
+                continue
             subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(x) for x in c], check=True)

@@ -32,7 +32,8 @@ def test_primary_hits_match_reference_hashes_at_full_size(fray, oracle, gpu, cas
 
 
 @pytest.mark.parametrize("scene,W,H", [("boxed.fray", 100, 75), ("forest.fray", 97, 61), ("smallpt.fray", 1, 1),
-                                       ("hw9/dragon.fray", 150, 100), ("cornell_box.fray", 47, 49), ("hw12/sphtri.fray", 64, 48)])
+                                       ("hw9/dragon.fray", 150, 100), ("cornell_box.fray", 47, 49), ("hw12/sphtri.fray", 64, 48),
+                                       ("hw10/bokeh.fray", 640, 480), ("hw9/axe_test.fray", 640, 480), ("hw9/nonconvex.fray", 640, 480)])
 def test_primary_hits_bit_exact_vs_oracle_ragged_sizes(fray, abi, oracle, gpu, scene, W, H):
     s = open_scene(fray, scene, W, H, wantAA=0)
     s.beginRender()
@@ -69,6 +70,9 @@ WHITTED = [
     ("smallpt.fray", 96, 72, dict(gi=0, wantAA=0)),                         # mirror + glass spheres under Whitted
     ("smallpt.fray", 40, 30, dict(gi=0, wantAA=1, maxTraceDepth=2)),
     ("forest.fray", 96, 72, dict(wantAA=0, interactive=0, stereoSeparation=0.25)),   # anaglyph: two eyes, saturation 0.1, colour masks
+    ("hw10/bokeh.fray", 96, 72, dict(wantAA=0, numDOFSamples=8)),           # as shipped but 8 lens samples: Cube - Cube CSG floor, Layered, Phong, cubemap
+    ("hw9/axe_test.fray", 128, 96, dict()),                                  # as shipped (AA on): two KD meshes, checker floor, cubemap
+    ("hw9/nonconvex.fray", 128, 96, dict()),                                 # as shipped: one small mesh over a checker floor (the other four figures are commented out in the file)
 ]
 
 

@@ -220,7 +220,8 @@ def test_bmp_loader_and_bump_differentiation(fray, tmp_path):
 
 def test_shipped_scenes_parse(fray):
     for name, nodes, lights in [("boxed.fray", 9, 2), ("zaphod.fray", 1, 1), ("cornell_box.fray", 7, 1), ("forest.fray", 4, 1),
-                                ("smallpt.fray", 7, 1), ("hw9/dragon.fray", 2, 1), ("hw12/sphtri.fray", 1, 3)]:
+                                ("smallpt.fray", 7, 1), ("hw9/dragon.fray", 2, 1), ("hw12/sphtri.fray", 1, 3),
+                                ("hw10/bokeh.fray", 2, 1), ("hw9/axe_test.fray", 3, 1), ("hw9/nonconvex.fray", 2, 1)]:   # all ten scenes fray ships (nonconvex: four of its five figures sit inside a block comment)
         s = open_scene(fray, name)
         assert (s.desc.n_nodes, s.desc.n_lights) == (nodes, lights), name
         s.close()

@@ -21,7 +21,7 @@ def rms(a, b):
     return np.sqrt(((a.astype(np.float64) - b.astype(np.float64)) ** 2).mean(axis=(0, 1)))
 
 
-@pytest.mark.parametrize("case", GOLD["cases"], ids=lambda c: "%s-%dx%d" % (c["scene"], c["w"], c["h"]))
+@pytest.mark.parametrize("case", GOLD["cases"] + GOLD.get("cases_ref", []), ids=lambda c: "%s-%dx%d" % (c["scene"], c["w"], c["h"]))
 def test_primary_hits_match_reference_hashes_at_full_size(fray, oracle, gpu, case):
     s = open_scene(fray, case["scene"], case["w"], case["h"], wantAA=0)
     s.beginRender()

@@ -11,7 +11,7 @@ from conftest import ROOT, open_scene
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "primary_hashes.json")))
 
 
-@pytest.mark.parametrize("case", GOLD["cases"], ids=lambda c: "%s-%dx%d" % (c["scene"], c["w"], c["h"]))
+@pytest.mark.parametrize("case", GOLD["cases"] + GOLD.get("cases_ref", []), ids=lambda c: "%s-%dx%d" % (c["scene"], c["w"], c["h"]))
 def test_oracle_primary_hits_match_reference_hashes(fray, abi, oracle, case):
     s = open_scene(fray, case["scene"], case["w"], case["h"], wantAA=0)
     ids, dist, st = oracle.render(s.desc, abi.MODE_PRIMARY_ID)

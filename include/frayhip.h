@@ -262,6 +262,9 @@ void frayhip_scene_destroy(frayhip_scene* s);
  * Camera::beginFrame re-derives everything per frame anyway).  Either pointer may be NULL. */
 int  frayhip_scene_set_view(frayhip_scene* s, const frayhip_camera* camera, const frayhip_settings* settings);
 
+/* Threads: a frayhip_scene renders one frame at a time (it owns one workspace and one set of
+ * counters), as the reference calls render() from one thread at a time (main.cpp:407-412,448);
+ * different scenes may be driven from different threads.  frayhip_last_error() is per thread. */
 /* Blocking render.  Any output pointer may be NULL.  Host buffers, row-major:
  *   rgb      W*H*3 float  -- `vfb` (main.cpp:53,360), linear, unclamped
  *   hit_id   W*H   int32  -- node index, -1 miss, -2-i light i   (MODE_PRIMARY_ID)

@@ -246,6 +246,18 @@ def main():
             out["roofline_shadow_kernel"] = {"bound": "hbm", "kernel": "k_pt_shadow", "achieved": sb / (sms * 1e-3) / 1e9, "peak": 8000.0,
                                              "unit": "GB/s", "frac": sb / (sms * 1e-3) / 1e9 / 8000.0, "alg_bytes_per_launch": sb,
                                              "avg_launch_ms": sms, "launches_per_step": shadow_launches / args.steps}
+        # FP64 rate beside the byte rate.  Operation counts per test are the survey's
+        # (Node::intersect ~90, triangle ~45, box ~30 FP64 operations); the reference build has no FMA,
+        # so the ceiling for this arithmetic is one operation per lane per issue: half of the 78.6 TFLOP/s
+        # (FMA = 2) vector FP64 peak.  Rank 0's share over the frame time.
+        try:
+            ops = (90.0 * st_counts["node_tests"] + 45.0 * st_counts["tri_tests"] + 30.0 * st_counts["prim_tests"] +
+                   30.0 * (st_counts["node_tests"] + 2.0 * st_counts["kd_inner_visits"]))
+            tf = ops / (ms_per_step * 1e-3) / 1e12
+            out["fp64"] = {"achieved": tf, "peak": 39.3, "unit": "TFLOP/s", "frac": tf / 39.3,
+                           "note": "algorithmic FP64 operations (survey's per-test counts) / frame time; peak = vector FP64 without FMA (78.6 / 2)"}
+        except KeyError:
+            pass
         if check is not None:
             out["gathered_frame_equals_single_rank_frame"] = check
         # HBM traffic of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <functional>
 
 #include "capi_common.h"
 #include "kernels.hpp"
@@ -189,11 +190,24 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     if (desc->abi_version != FRAYHIP_ABI_VERSION) { set_error("frayhip_scene_create: ABI version mismatch"); return FRAYHIP_E_ARG; }
     const frayhip_scene_desc& d = *desc;
     // ---- what the device path implements ----
-    for (int i = 0; i < d.n_csgs; i++)
-        if (d.geoms[d.csgs[i].left].kind == FRAYHIP_GEOM_CSG || d.geoms[d.csgs[i].right].kind == FRAYHIP_GEOM_CSG) {
-            set_error("frayhip_scene_create: nested CSG operands are not implemented on the device path yet");
-            return FRAYHIP_E_UNSUPPORTED;
-        }
+    {   // CsgOp trees: the device unrolls the Geometry::intersect recursion FRAY_CSG_DEPTH levels deep
+        std::vector<int> levels(d.n_csgs, 0);      // 0 = not computed yet
+        std::function<int(int, int)> depth = [&](int i, int guard) -> int {
+            if (guard > d.n_csgs) return 1 << 20;   // a cycle cannot come out of the parser, but a hand-made description could hold one
+            if (levels[i]) return levels[i];
+            int m = 1;
+            for (int side = 0; side < 2; side++) {
+                const frayhip_geom_ref& g = d.geoms[side == 0 ? d.csgs[i].left : d.csgs[i].right];
+                if (g.kind == FRAYHIP_GEOM_CSG) m = std::max(m, 1 + depth(g.index, guard + 1));
+            }
+            return levels[i] = m;
+        };
+        for (int i = 0; i < d.n_csgs; i++)
+            if (depth(i, 0) > FRAY_CSG_DEPTH) {
+                set_error("frayhip_scene_create: CSG operands nested more than " + std::to_string(FRAY_CSG_DEPTH) + " levels deep are not implemented on the device path");
+                return FRAYHIP_E_UNSUPPORTED;
+            }
+    }
     frayhip_scene* sc = new frayhip_scene();
     for (int i = 0; i < d.n_nodes; i++) {
         int k = d.geoms[d.nodes[i].geom].kind;

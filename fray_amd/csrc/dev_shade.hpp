@@ -76,13 +76,12 @@ FD void finalize_hit(const DScene& S, const HitRec& h, V3 o, V3 d, bool needUV, 
     } else if ((ST & 2) && N.geomKind == 4) {
         const FRAY_RO DCsg& G = S.csgs[N.geomIndex];
         GHit g;
-        int which = 0;
         bool env = false;
         Cnt dummy;
         dummy.envelope = 0;
-        csg_intersect<(ST & 2)>(S, G, ls, ldir, g, which, env, dummy);
+        csg_intersect<(ST & 2), FRAY_CSG_DEPTH - 1>(S, G, ls, ldir, ray_rdir(ldir), g, env, dummy);
         ipl = g.ip;
-        prim_attributes(S, which == 0 ? G.leftKind : G.rightKind, which == 0 ? G.leftIndex : G.rightIndex, ipl, g.code, g.l2, g.l3, needUV, nl, info);
+        prim_attributes(S, g.leafKind, g.leafIndex, ipl, g.code, g.l2, g.l3, needUV, nl, info);
     } else {
         prim_attributes(S, N.geomKind, N.geomIndex, ipl, h.tri, h.l2, h.l3, needUV, nl, info);
     }

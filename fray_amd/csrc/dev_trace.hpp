@@ -249,7 +249,7 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
 // One intersection as <Geometry>::intersect reports it, reduced to what later stages rebuild the
 // full IntersectionInfo from: dist (the geometry's own info.dist), the local hit point, and a code
 // (cube side / triangle index) with the triangle's barycentrics.
-struct GHit { double dist; V3 ip; int code; double l2, l3; };
+struct GHit { double dist; V3 ip; int code; double l2, l3; int leafKind, leafIndex; };   // leaf: the non-CSG geometry that produced it
 
 FD bool cube_intersect(const FRAY_RO DCube& Cb, V3 s, V3 d, GHit& h)   // Cube::intersect, geometry.cpp:85-137
 {
@@ -324,26 +324,44 @@ FD bool prim_intersect(const DScene& S, int kind, int index, V3 s, V3 d, V3 rd, 
 }
 
 #define FRAY_CSG_MAX 16   // intersections kept per operand (the reference keeps up to 30)
+#ifndef FRAY_CSG_DEPTH
+#define FRAY_CSG_DEPTH 3  // CsgOp levels: 1 = operands are plain geometries, 3 = a CSG of CSGs of CSGs (deeper scenes are rejected at upload)
+#endif
 
-// CsgOp::intersect (geometry.cpp:139-194).  `which` of the winner: 0 = left operand, 1 = right.
+template <int ST, int LEVELS>
+FD bool csg_intersect(const DScene& S, const FRAY_RO DCsg& G, V3 s, V3 d, V3 rd, GHit& win, bool& envelope, Cnt& c);
+
+// operand->intersect(ray, info) of a CsgOp whose own subtree has LEVELS more CsgOp levels available.
+// The reference recurses through the Geometry virtual (geometry.cpp:146); here the recursion is
+// unrolled by the template parameter, one call site per level.
+template <int ST, int LEVELS>
+FD bool operand_intersect(const DScene& S, int kind, int index, V3 s, V3 d, V3 rd, GHit& h, bool& envelope, Cnt& c)
+{
+    if (kind == 4) {
+        if constexpr (LEVELS > 0) return csg_intersect<ST, LEVELS - 1>(S, S.csgs[index], s, d, rd, h, envelope, c);
+        envelope = true;          // unreachable: frayhip_scene_create rejects deeper trees
+        return false;
+    }
+    const bool ok = prim_intersect<ST>(S, kind, index, s, d, rd, h, c);
+    h.leafKind = kind; h.leafIndex = index;
+    return ok;
+}
+
+// CsgOp::intersect (geometry.cpp:139-194).  The winner carries the leaf geometry that produced it.
 // Hits are ordered with a stable insertion sort, which is what libstdc++'s std::sort does for up
 // to 16 elements; beyond that equal-distance ties could be ordered differently, and more than
 // FRAY_CSG_MAX hits on one operand are reported through `envelope`.
-template <int ST>
-FD bool csg_intersect(const DScene& S, const FRAY_RO DCsg& G, V3 s, V3 d, GHit& win, int& which, bool& envelope, Cnt& c)
+template <int ST, int LEVELS>
+FD bool csg_intersect(const DScene& S, const FRAY_RO DCsg& G, V3 s, V3 d, V3 rd, GHit& win, bool& envelope, Cnt& c)
 {
     GHit hits[2 * FRAY_CSG_MAX];
     unsigned char side[2 * FRAY_CSG_MAX];
     int n = 0, cnt[2] = {0, 0};
-    V3 rd;
-    rd.x = fabs(d.x) > 1e-12 ? 1.0 / d.x : 1e12;
-    rd.y = fabs(d.y) > 1e-12 ? 1.0 / d.y : 1e12;
-    rd.z = fabs(d.z) > 1e-12 ? 1.0 / d.z : 1e12;
     for (int op = 0; op < 2; op++) {   // findAllIntersections, geometry.cpp:139-159
         const int kind = op == 0 ? G.leftKind : G.rightKind, index = op == 0 ? G.leftIndex : G.rightIndex;
         V3 start = s;
         GHit h;
-        while (prim_intersect<ST>(S, kind, index, start, d, rd, h, c)) {
+        while (operand_intersect<ST, LEVELS>(S, kind, index, start, d, rd, h, envelope, c)) {
             if (cnt[op] == FRAY_CSG_MAX) { envelope = true; break; }
             if (cnt[op] > 0) h.dist = length(h.ip - s);
             hits[n] = h; side[n] = (unsigned char)op; n++; cnt[op]++;
@@ -362,9 +380,19 @@ FD bool csg_intersect(const DScene& S, const FRAY_RO DCsg& G, V3 s, V3 d, GHit& 
     const bool cur = bop(inL, inR);
     for (int i = 0; i < n; i++) {
         if (side[i] == 0) inL = !inL; else inR = !inR;
-        if (bop(inL, inR) != cur) { win = hits[i]; which = side[i]; return true; }
+        if (bop(inL, inR) != cur) { win = hits[i]; return true; }
     }
     return false;
+}
+
+// RRay::prepareForTracing (bbox.h:49-54) of a local ray, for the meshes below a CSG node
+FD V3 ray_rdir(V3 d)
+{
+    V3 rd;
+    rd.x = fabs(d.x) > 1e-12 ? 1.0 / d.x : 1e12;
+    rd.y = fabs(d.y) > 1e-12 ? 1.0 / d.y : 1e12;
+    rd.z = fabs(d.z) > 1e-12 ? 1.0 / d.z : 1e12;
+    return rd;
 }
 
 // Geometry part of Node::intersect for node N on the local ray; on a hit returns the local
@@ -419,9 +447,8 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, LocalRay& lr, V3
     }
     if ((ST & 2) && N.geomKind == 4) {   // CSG: the winner is re-derived in finalize_hit
         GHit h;
-        int which = 0;
         bool env = false;
-        if (!csg_intersect<ST>(S, S.csgs[N.geomIndex], ls, ld, h, which, env, c)) return false;
+        if (!csg_intersect<ST, FRAY_CSG_DEPTH - 1>(S, S.csgs[N.geomIndex], ls, ld, ray_rdir(ld), h, env, c)) return false;
         if (env) c.envelope = 1;
         ipl = h.ip;
         tri = h.code;

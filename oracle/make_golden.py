@@ -34,6 +34,7 @@ CASES = [
     ("bokeh_dof", "hw10/bokeh.fray", 48, 36, "wantAA=0;numDOFSamples=6", 3, 300),      # Cube - Cube CSG, Layered(Refl over textured Lambert), Phong, DOF
     ("axe_whitted", "hw9/axe_test.fray", 48, 36, "wantAA=0", 3, 300),
     ("nonconvex_aa", "hw9/nonconvex.fray", 48, 36, "wantAA=1", 3, 200),
+    ("csg_nested", "../tests/scenes/csg_nested.fray", 60, 45, "wantAA=0", 2, 400),       # this repository's scene: CsgOp trees three levels deep
 ]
 
 

@@ -427,13 +427,34 @@ def test_pack_unpack_buckets(fray, gpu):
     assert torch.equal(out, frame)
 
 
+@pytest.mark.parametrize("gi", [0, 1])
+def test_nested_csg_vs_oracle(fray, abi, oracle, gpu, gi):
+    """CsgOp trees up to three levels deep (tests/scenes/csg_nested.fray; the oracle equals the reference's own
+    CsgOp code on it: tests/golden/ref_csg_nested.npz)."""
+    s = fray.Scene.parseScene(os.path.join(ROOT, "tests", "scenes", "csg_nested.fray"))
+    s.settings.gi, s.settings.numPaths = gi, 5
+    s.beginRender()
+    ids, dist, st = s.primary_hits(stats=True)
+    oi, od, ost = oracle.render(s.desc, abi.MODE_PRIMARY_ID)
+    assert set(np.unique(oi)) >= {0, 1, 2, 3}
+    assert np.array_equal(ids, oi) and np.array_equal(dist, od)
+    for k in COUNTERS:
+        assert st[k] == ost[k], k
+    img, _ = s.render(seed=42)
+    ref, _ = oracle.render(s.desc, abi.MODE_RENDER, seed=42)
+    assert ref.mean() > 0.02 and np.all(np.isfinite(img))
+    assert np.all(rms(img, ref) <= RMS_TOL), rms(img, ref)
+    s.close()
+
+
 def test_unsupported_features_fail_loudly(fray, abi, gpu, tmp_path):
     f = tmp_path / "nested.fray"
-    f.write_text("Camera camera {\n\tposition (0,0,-5)\n}\nCube a {\n}\nSphere b {\n}\nCsgPlus ab {\n\tleft a\n\tright b\n}\n"
-                 "CsgMinus abc {\n\tleft ab\n\tright b\n}\nLambert l {\n}\nNode n {\n\tgeometry abc\n\tshader l\n}\n")
+    f.write_text("Camera camera {\n\tposition (0,0,-5)\n}\nCube a {\n}\nSphere b {\n}\nCsgPlus l1 {\n\tleft a\n\tright b\n}\n"
+                 "CsgMinus l2 {\n\tleft l1\n\tright b\n}\nCsgAnd l3 {\n\tleft a\n\tright l2\n}\nCsgPlus l4 {\n\tleft l3\n\tright l1\n}\n"
+                 "Lambert l {\n}\nNode n {\n\tgeometry l4\n\tshader l\n}\n")
     s = fray.Scene.parseScene(str(f))
     with pytest.raises(fray.FrayError) as e:
-        s.beginRender()                                         # CSG of CSG
+        s.beginRender()                                         # four CsgOp levels: one more than the device unrolls
     assert e.value.code == abi.E_UNSUPPORTED
     s3 = open_scene(fray, "boxed.fray", 32, 32)
     with pytest.raises(fray.FrayError):

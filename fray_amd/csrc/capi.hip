@@ -130,13 +130,13 @@ bool shader_uses_uv(const frayhip_scene_desc& d, int s, int depth = 0)
     return false;
 }
 
-// Grid of a persistent kernel (k_primary, k_whitted: waves claim work from DStats.cursor): exactly the
-// blocks that are resident at once -- a 256-thread block is one wave per SIMD, so `wavesPerSimd`
-// blocks per compute unit.
 // d_stats: two DStats blocks, then (256-byte aligned) the work cursors; one memset clears all of it per frame
 constexpr size_t kCursorOffset = (2 * sizeof(DStats) + 255) / 256 * 256;
 constexpr size_t kStatsBytes = kCursorOffset + sizeof(DCursors);
 
+// Grid of a persistent kernel (k_primary, k_whitted: waves claim tiles from DCursors): exactly the
+// blocks that are resident at once -- a 256-thread block is one wave per SIMD, so `wavesPerSimd`
+// blocks per compute unit.
 int persistent_grid(size_t n, int wavesPerSimd)
 {
     static int cus = 0;
@@ -170,6 +170,94 @@ int grid_for(size_t n)
     return (int)blocks;
 }
 
+
+// A description can come from any host, not only from frayhip_scene_parse: every
+// index the kernels will follow is range-checked here, because an out-of-range one would be a wild
+// device read.  Returns an empty string when the description is sound.
+std::string validate_desc(const frayhip_scene_desc& d)
+{
+    auto bad = [](const char* what, long long i) { return std::string("frayhip_scene_create: ") + what + " (element " + std::to_string(i) + ")"; };
+    const int32_t counts[] = {d.n_nodes, d.n_geoms, d.n_planes, d.n_spheres, d.n_cubes, d.n_csgs, d.n_meshes, d.n_shaders, d.n_layers, d.n_textures, d.n_lights};
+    for (int32_t c : counts) if (c < 0) return "frayhip_scene_create: negative element count";
+    if (d.n_texels < 0) return "frayhip_scene_create: negative texel count";
+    const void* arrays[] = {d.nodes, d.geoms, d.planes, d.spheres, d.cubes, d.csgs, d.meshes, d.shaders, d.layers, d.textures, d.lights};
+    for (int k = 0; k < 11; k++) if (counts[k] > 0 && !arrays[k]) return "frayhip_scene_create: null array with a non-zero count";
+    if (d.n_texels > 0 && !d.texels) return "frayhip_scene_create: null texel pool";
+    const int32_t perKind[5] = {d.n_planes, d.n_spheres, d.n_cubes, d.n_meshes, d.n_csgs};
+    for (int i = 0; i < d.n_geoms; i++) {
+        const frayhip_geom_ref& g = d.geoms[i];
+        if (g.kind < 0 || g.kind > 4 || g.index < 0 || g.index >= perKind[g.kind]) return bad("geometry reference out of range", i);
+    }
+    for (int i = 0; i < d.n_csgs; i++) {
+        const frayhip_csg& c = d.csgs[i];
+        if (c.op < 0 || c.op > 2 || c.left < 0 || c.left >= d.n_geoms || c.right < 0 || c.right >= d.n_geoms) return bad("CSG operand out of range", i);
+    }
+    auto texel_range_ok = [&](int64_t off, int32_t w, int32_t h) {
+        if (w < 0 || h < 0 || off < 0) return false;
+        return off + (int64_t)w * h * 3 <= d.n_texels;
+    };
+    for (int i = 0; i < d.n_textures; i++) {
+        const frayhip_texture& t = d.textures[i];
+        if (t.kind < 0 || t.kind > 3) return bad("unknown texture kind", i);
+        if ((t.kind == FRAYHIP_TEX_BITMAP || t.kind == FRAYHIP_TEX_BUMP) && !texel_range_ok(t.texel_offset, t.width, t.height)) return bad("texture texels outside the pool", i);
+    }
+    for (int i = 0; i < d.n_layers; i++) {
+        const frayhip_layer& L = d.layers[i];
+        if (L.shader < 0 || L.shader >= d.n_shaders || L.texture < -1 || L.texture >= d.n_textures) return bad("layer reference out of range", i);
+    }
+    for (int i = 0; i < d.n_shaders; i++) {
+        const frayhip_shader& sh = d.shaders[i];
+        if (sh.kind < 0 || sh.kind > 5) return bad("unknown shader kind", i);
+        if (sh.texture < -1 || sh.texture >= d.n_textures) return bad("shader texture out of range", i);
+        if (sh.kind == FRAYHIP_SHADER_LAYERED && (sh.layer_begin < 0 || sh.layer_count < 0 || (int64_t)sh.layer_begin + sh.layer_count > d.n_layers)) return bad("layer range out of bounds", i);
+        if (sh.kind == FRAYHIP_SHADER_REFL && sh.numSamples < 0) return bad("negative numSamples", i);
+    }
+    for (int i = 0; i < d.n_nodes; i++) {
+        const frayhip_node& n = d.nodes[i];
+        if (n.geom < 0 || n.geom >= d.n_geoms || n.shader < 0 || n.shader >= d.n_shaders || n.bump_tex < -1 || n.bump_tex >= d.n_textures) return bad("node reference out of range", i);
+    }
+    for (int i = 0; i < d.n_lights; i++) {
+        const frayhip_light& L = d.lights[i];
+        if (L.kind < 0 || L.kind > 1) return bad("unknown light kind", i);
+        if (L.kind == FRAYHIP_LIGHT_RECT && (L.xSubd <= 0 || L.ySubd <= 0 || (int64_t)L.xSubd * L.ySubd > (1 << 20))) return bad("bad RectLight subdivision", i);
+    }
+    if (d.environment.present && d.environment.loaded)
+        for (int f = 0; f < 6; f++)
+            if (d.environment.width[f] <= 0 || d.environment.height[f] <= 0 || !texel_range_ok(d.environment.texel_offset[f], d.environment.width[f], d.environment.height[f]))
+                return bad("environment face outside the texel pool", f);
+    for (int i = 0; i < d.n_meshes; i++) {
+        const frayhip_mesh& m = d.meshes[i];
+        if (m.n_vertices < 0 || m.n_normals < 0 || m.n_uvs < 0 || m.n_triangles < 0 || m.n_kdnodes < 0 || m.n_trirefs < 0) return bad("negative mesh count", i);
+        if ((m.n_vertices && !m.vertices) || (m.n_normals && !m.normals) || (m.n_uvs && !m.uvs) || (m.n_triangles && !m.triangles) ||
+            (m.n_kdnodes && !m.kdnodes) || (m.n_trirefs && !m.trirefs)) return bad("null mesh array with a non-zero count", i);
+        for (int t = 0; t < m.n_triangles; t++) {
+            const frayhip_triangle& T = m.triangles[t];
+            for (int k = 0; k < 3; k++) {
+                if (T.v[k] < 0 || T.v[k] >= m.n_vertices) return bad("triangle vertex index out of range in mesh", i);
+                if (m.n_normals > 0 && (T.n[k] < 0 || T.n[k] >= m.n_normals)) return bad("triangle normal index out of range in mesh", i);
+                if (m.n_uvs > 0 && (T.t[k] < 0 || T.t[k] >= m.n_uvs)) return bad("triangle uv index out of range in mesh", i);
+            }
+        }
+        if (m.has_kd) {
+            if (m.n_kdnodes <= 0) return bad("has_kd without nodes in mesh", i);
+            for (int k = 0; k < m.n_kdnodes; k++) {
+                const frayhip_kdnode& n = m.kdnodes[k];
+                if (n.parent < -1 || n.parent >= k || (k == 0) != (n.parent == -1)) return bad("KD parent link is not a tree in mesh", i);
+                if (n.axis == 3) {
+                    if (n.tri_begin < 0 || n.tri_count < 0 || (int64_t)n.tri_begin + n.tri_count > m.n_trirefs) return bad("KD leaf range out of bounds in mesh", i);
+                } else if (n.axis >= 0 && n.axis <= 2) {
+                    // children lie after their parent (pre-order) and point back to it: the stackless walk climbs through these links
+                    if (n.child0 <= k || (int64_t)n.child0 + 1 >= m.n_kdnodes || m.kdnodes[n.child0].parent != k || m.kdnodes[n.child0 + 1].parent != k)
+                        return bad("KD child link is not a tree in mesh", i);
+                } else return bad("bad KD axis in mesh", i);
+            }
+            for (int r = 0; r < m.n_trirefs; r++) if (m.trirefs[r] < 0 || m.trirefs[r] >= m.n_triangles) return bad("KD triangle reference out of range in mesh", i);
+        }
+    }
+    if (d.settings.frameWidth <= 0 || d.settings.frameHeight <= 0) return "frayhip_scene_create: bad frame size";
+    return std::string();
+}
+
 }  // namespace
 
 extern "C" {
@@ -189,6 +277,10 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     if (!desc || !out) { set_error("frayhip_scene_create: null argument"); return FRAYHIP_E_ARG; }
     if (desc->abi_version != FRAYHIP_ABI_VERSION) { set_error("frayhip_scene_create: ABI version mismatch"); return FRAYHIP_E_ARG; }
     const frayhip_scene_desc& d = *desc;
+    {
+        const std::string why = validate_desc(d);
+        if (!why.empty()) { set_error(why); return FRAYHIP_E_ARG; }
+    }
     // ---- what the device path implements ----
     {   // CsgOp trees: the device unrolls the Geometry::intersect recursion FRAY_CSG_DEPTH levels deep
         std::vector<int> levels(d.n_csgs, 0);      // 0 = not computed yet

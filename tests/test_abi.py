@@ -3,6 +3,8 @@ import ctypes as C
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -81,3 +83,60 @@ def test_save_bmp_round_trips_through_the_loader(fray, tmp_path):
     tex = np.ctypeslib.as_array(s.desc.texels, shape=(s.desc.n_texels,))[t.texel_offset:t.texel_offset + W * H * 3].reshape(H, W, 3)
     want = np.floor(np.clip(rgb, 0, 1) * np.float32(255) + np.float32(0.5)) / np.float32(255)
     assert np.array_equal(tex, want.astype(np.float32))
+
+
+def test_scene_create_range_checks_a_description_before_touching_the_gpu(fray, abi):
+    """A description may come from any host: a bad index must be an error message, never a wild
+    device read.  Validation runs before the first HIP call, so this needs no GPU."""
+    import ctypes as C
+    from conftest import open_scene
+
+    def expect_rejected(mutate, needle, scene="boxed.fray"):
+        s = open_scene(fray, scene)
+        mutate(s.desc)
+        with pytest.raises(fray.FrayError) as e:
+            s.beginRender()
+        assert e.value.code == abi.E_ARG and needle in str(e.value), str(e.value)
+        s.close()
+
+    def poke(ptr_field, index, attr, value):
+        def f(d):
+            setattr(getattr(d, ptr_field)[index], attr, value)
+        return f
+
+    expect_rejected(poke("nodes", 0, "shader", 99), "node reference")
+    expect_rejected(poke("nodes", 1, "geom", -3), "node reference")
+    expect_rejected(poke("nodes", 0, "bump_tex", 1000), "node reference")
+    expect_rejected(poke("geoms", 0, "index", 12345), "geometry reference")
+    expect_rejected(poke("geoms", 0, "kind", 7), "geometry reference")
+    expect_rejected(poke("shaders", 0, "texture", 77), "shader texture")
+    expect_rejected(poke("lights", 0, "xSubd", 0), "RectLight")
+    expect_rejected(poke("textures", 0, "kind", 9), "texture kind")
+
+    def bad_tri(d):
+        d.meshes[0].triangles[5].v[1] = d.meshes[0].n_vertices
+    expect_rejected(bad_tri, "vertex index")
+
+    def bad_kd_child(d):
+        d.meshes[0].kdnodes[0].child0 = d.meshes[0].n_kdnodes
+    expect_rejected(bad_kd_child, "KD child link")
+
+    def bad_kd_leaf(d):
+        m = d.meshes[0]
+        for k in range(m.n_kdnodes):
+            if m.kdnodes[k].axis == 3 and m.kdnodes[k].tri_count > 0:
+                m.kdnodes[k].tri_begin = m.n_trirefs
+                return
+    expect_rejected(bad_kd_leaf, "KD leaf range")
+
+    def bad_ref(d):
+        d.meshes[0].trirefs[3] = -1
+    expect_rejected(bad_ref, "KD triangle reference")
+
+    def bad_env(d):
+        d.environment.texel_offset[2] = d.n_texels
+    expect_rejected(bad_env, "environment face", scene="forest.fray")
+
+    def bad_frame(d):
+        d.settings.frameWidth = 0
+    expect_rejected(bad_frame, "frame size")

@@ -609,6 +609,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     F.bucketFirst = f->bucket_first;
     F.nBuckets = frayhip_bucket_count(W, H, F.bucketFirst, F.bucketStride);
     if (F.nBuckets < 0) { set_error("frayhip_render: bad bucket_first / bucket_stride"); return FRAYHIP_E_ARG; }
+    if ((long long)F.nBuckets * 2304 > (1ll << 30)) { set_error("frayhip_render: more than 2^30 pixels in one call (shard the frame with bucket_first / bucket_stride)"); return FRAYHIP_E_UNSUPPORTED; }
     int spp = set.wantAA ? 5 : 1;                                   // main.cpp:395-400
     if (sc->camera.dof) spp = std::max(spp, sc->camera.numDOFSamples);
     if (set.gi) spp = std::max(spp, set.numPaths);
@@ -663,7 +664,6 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, ((size_t)1 << 26) / (size_t)nItems);
             if (chunk > spp) chunk = spp;
             while (chunk > 1 && (size_t)nItems * chunk > ((size_t)1 << 30)) chunk /= 2;   // slots are 32-bit
-            if ((size_t)nItems > ((size_t)1 << 30)) { set_error("frayhip_render: frame too large for one call (more than 2^30 pixels per rank)"); return FRAYHIP_E_UNSUPPORTED; }
             const size_t nPaths = (size_t)nItems * chunk;
             // per-wave segments round their share up to a multiple of 64: one extra wave-load per wave of the grid
             const size_t nQueue = nPaths + (size_t)grid_for(nPaths) * 4 * 128;

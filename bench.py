@@ -89,11 +89,55 @@ def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0):
     _, st1 = orc.render(s.desc, mode, seed=seed, bucket_first=0, bucket_stride=stride1, threads=1)
     dt1 = max(time.time() - t0, 1e-6)
     s.close()
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    ref_cmp = reference_object_code_rate(fray_amd, abi, orc, wl, seed)
+    return {**({"reference_object_code": ref_cmp} if ref_cmp else {}),
+            "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": "%d of %d buckets (every %d-th 48x48 bucket) of the same frame, all spp, %.1f s, %d threads" % (n_b, nb, stride, dt, threads),
             "frame_ms_extrapolated": dt * 1e3 * nb / n_b,
             "one_thread_mrays_per_s": (st1["closest_rays"] + st1["shadow_rays"]) / dt1 / 1e6,
             "one_thread_sample": "%d buckets, %.1f s" % (len(range(0, nb, stride1)), dt1)}
+
+
+REF_TIMER = r"""
+import ctypes as C, sys, time
+import numpy as np
+lib = C.CDLL(sys.argv[1])
+lib.ref_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p]
+lib.ref_render.argtypes = [C.c_void_p, C.c_uint]
+W, H = int(sys.argv[3]), int(sys.argv[4])
+assert lib.ref_load(sys.argv[2].encode(), W, H, sys.argv[5].encode()) == 0
+img = np.zeros((H, W, 3), np.float32)
+t0 = time.time()
+lib.ref_render(img.ctypes.data, int(sys.argv[6]))
+sys.stderr.write("REFTIME %.6f\n" % (time.time() - t0))
+"""
+
+
+def reference_object_code_rate(fray_amd, abi, orc, wl, seed, W=96, H=96):
+    """How the port compares with the reference's own code: oracle/_ref (the reference's geometry / shader /
+    light / camera object code under the restated sample loop, oracle/ref_glue.cpp) and the oracle render the
+    same small frame of this workload's scene on ONE thread; both produce the same picture, so the oracle's ray
+    count applies to both.  Skipped when oracle/_ref was not built (it needs the reference tree at build time)."""
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "_ref", "libfray_ref.so")
+    name, _, _, over, _ = wl
+    if not os.path.exists(so) or "dof" in over:
+        return None
+    ov = ";".join("%s=%s" % (k, v) for k, v in over.items())
+    try:
+        r = subprocess.run([sys.executable, "-c", REF_TIMER, so, os.path.join(ROOT, "scenes", name), str(W), str(H), ov, str(seed)],
+                           capture_output=True, text=True, timeout=120, env={**os.environ, "OMP_NUM_THREADS": "1"})
+        t_ref = float([l for l in r.stderr.splitlines() if l.startswith("REFTIME ")][-1].split()[1])
+    except (subprocess.SubprocessError, IndexError, ValueError, OSError):
+        return None
+    s = open_scene(fray_amd, name, W, H, over)
+    t0 = time.time()
+    _, st = orc.render(s.desc, abi.MODE_RENDER, seed=seed, threads=1)
+    t_port = max(time.time() - t0, 1e-6)
+    s.close()
+    rays = st["closest_rays"] + st["shadow_rays"]
+    return {"frame": "%dx%d, same scene and spp" % (W, H), "threads": 1,
+            "reference_mrays_per_s": rays / max(t_ref, 1e-6) / 1e6, "port_mrays_per_s": rays / t_port / 1e6}
 
 
 def main():

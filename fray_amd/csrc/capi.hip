@@ -48,6 +48,10 @@ void putX(DXform& X, const frayhip_transform& T)
 
 }  // namespace
 
+#ifndef FRAY_PT_LANES
+#define FRAY_PT_LANES 3   // measured on the headline frame: 1 -> 150 ms, see DESIGN.md section 4
+#endif
+
 struct frayhip_scene {
     void* d_arena = nullptr;
     size_t arena_bytes = 0;
@@ -63,6 +67,9 @@ struct frayhip_scene {
     QMeta* d_qmeta = nullptr;         // [3] segment tables: ping-pong path queues + shadow queue
     hipEvent_t evA = nullptr, evB = nullptr;
     std::vector<hipEvent_t> evPool, evPoolShadow;
+    // path tracing: batches of a frame run on FRAY_PT_LANES streams at once (lane 0 = the caller's stream)
+    hipStream_t laneStream[FRAY_PT_LANES] = {};
+    hipEvent_t evLaneStart = nullptr, evResolved[FRAY_PT_LANES] = {};
 };
 
 namespace {
@@ -170,6 +177,16 @@ int grid_for(size_t n)
     return (int)blocks;
 }
 
+
+bool create_lanes(frayhip_scene* sc)
+{
+    if (hipEventCreateWithFlags(&sc->evLaneStart, hipEventDisableTiming) != hipSuccess) return false;
+    for (int k = 0; k < FRAY_PT_LANES; k++) {
+        if (k > 0 && hipStreamCreateWithFlags(&sc->laneStream[k], hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&sc->evResolved[k], hipEventDisableTiming) != hipSuccess) return false;
+    }
+    return true;
+}
 
 // A description can come from any host, not only from frayhip_scene_parse: every
 // index the kernels will follow is range-checked here, because an out-of-range one would be a wild
@@ -509,8 +526,8 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     sc->camera = d.camera;
     sc->settings = d.settings;
     // [0] everything but k_pt_shadow, [1] k_pt_shadow
-    if (hipMalloc((void**)&sc->d_stats, kStatsBytes) != hipSuccess || hipMalloc((void**)&sc->d_qmeta, 3 * sizeof(QMeta)) != hipSuccess ||
-        hipEventCreate(&sc->evA) != hipSuccess || hipEventCreate(&sc->evB) != hipSuccess) {
+    if (hipMalloc((void**)&sc->d_stats, kStatsBytes) != hipSuccess || hipMalloc((void**)&sc->d_qmeta, 3 * FRAY_PT_LANES * sizeof(QMeta)) != hipSuccess ||
+        hipEventCreate(&sc->evA) != hipSuccess || hipEventCreate(&sc->evB) != hipSuccess || !create_lanes(sc)) {
         set_error("frayhip_scene_create: could not allocate the per-scene device state");
         frayhip_scene_destroy(sc);
         return FRAYHIP_E_NOMEM;
@@ -537,6 +554,11 @@ void frayhip_scene_destroy(frayhip_scene* s)
     if (s->d_qmeta) (void)hipFree(s->d_qmeta);
     if (s->evA) (void)hipEventDestroy(s->evA);
     if (s->evB) (void)hipEventDestroy(s->evB);
+    if (s->evLaneStart) (void)hipEventDestroy(s->evLaneStart);
+    for (int k = 0; k < FRAY_PT_LANES; k++) {
+        if (s->evResolved[k]) (void)hipEventDestroy(s->evResolved[k]);
+        if (s->laneStream[k]) (void)hipStreamDestroy(s->laneStream[k]);
+    }
     for (auto e : s->evPool) (void)hipEventDestroy(e);
     for (auto e : s->evPoolShadow) (void)hipEventDestroy(e);
     delete s;
@@ -661,62 +683,92 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             }
         } else if (nItems > 0) {
             if (set.maxTraceDepth > 60) { set_error("frayhip_render: maxTraceDepth above 60 is not supported"); return FRAYHIP_E_UNSUPPORTED; }
-            int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, ((size_t)1 << 26) / (size_t)nItems);
+            // Batches of `chunk` samples per pixel; up to FRAY_PT_LANES batches are in flight at once, each on its own
+            // stream with its own queues, so one batch's launch gaps, scans and kernel tails are filled by the others'
+            // blocks.  Only the resolves are ordered (evResolved): the per-pixel sum runs in sample order.
+            const size_t budget = (size_t)1 << 26;                        // paths in flight over all lanes
+            int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / FRAY_PT_LANES / (size_t)nItems);
             if (chunk > spp) chunk = spp;
+            if (f->spp_chunk <= 0 && spp >= 2 * FRAY_PT_LANES && chunk * FRAY_PT_LANES > spp) chunk = (spp + FRAY_PT_LANES - 1) / FRAY_PT_LANES;   // enough batches to fill the lanes
             while (chunk > 1 && (size_t)nItems * chunk > ((size_t)1 << 30)) chunk /= 2;   // slots are 32-bit
+            const int nBatches = (spp + chunk - 1) / chunk;
+            const int nLanes = std::min(nBatches, FRAY_PT_LANES);
             const size_t nPaths = (size_t)nItems * chunk;
             // per-wave segments round their share up to a multiple of 64: one extra wave-load per wave of the grid
             const size_t nQueue = nPaths + (size_t)grid_for(nPaths) * 4 * 128;
             const bool stereo = sc->camera.stereoSeparation > 0;
-            const size_t need = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + (size_t)nItems * 12 + nPaths * 4 + 8192 +
-                                (stereo ? nPaths * (12 + 6 * 8 + 6 * 4) + 16 * 256 : 0);
-            int rc = ensure_work(sc, need);
+            const size_t laneBytes = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + nPaths * 4 + 4096 +
+                                     (stereo ? nPaths * (12 + 6 * 8 + 6 * 4) + 16 * 256 : 0);
+            int rc = ensure_work(sc, (size_t)nLanes * laneBytes + (size_t)nItems * 12 + 4096);
             if (rc) return rc;
-            PathQueue Q[2];
+            struct Lane {
+                hipStream_t stream;
+                PathQueue Q[2];
+                ShadowQueue SQ;
+                float *sampleRad, *sampleRadR;
+                uint32_t* x397;
+                StereoBuf SB;
+                QMeta* meta;
+            } lane[FRAY_PT_LANES];
             unsigned char* p = (unsigned char*)sc->d_work;
-            p = carve_queue(p, nQueue, Q[0]);
-            p = carve_queue(p, nQueue, Q[1]);
-            ShadowQueue SQ;
-            p = carve_shadow(p, nQueue, SQ);
-            float* sampleRad = (float*)p; p += (nPaths * 12 + 255) / 256 * 256;
             float* sum = (float*)p; p += ((size_t)nItems * 12 + 255) / 256 * 256;
-            uint32_t* x397 = (uint32_t*)p; p += (nPaths * 4 + 255) / 256 * 256;
-            StereoBuf SB{}, SBnone{};
-            float* sampleRadR = nullptr;
-            if (stereo) {
-                sampleRadR = (float*)p; p += (nPaths * 12 + 255) / 256 * 256;
-                for (int k = 0; k < 6; k++) { SB.r[k] = (double*)p; p += (nPaths * 8 + 255) / 256 * 256; }
-                for (int k = 0; k < 6; k++) { SB.g[k] = (uint32_t*)p; p += (nPaths * 4 + 255) / 256 * 256; }
+            for (int k = 0; k < nLanes; k++) {
+                Lane& L = lane[k];
+                L.stream = k == 0 ? stream : sc->laneStream[k];
+                L.meta = sc->d_qmeta + 3 * k;
+                p = carve_queue(p, nQueue, L.Q[0]);
+                p = carve_queue(p, nQueue, L.Q[1]);
+                p = carve_shadow(p, nQueue, L.SQ);
+                L.sampleRad = (float*)p; p += (nPaths * 12 + 255) / 256 * 256;
+                L.x397 = (uint32_t*)p; p += (nPaths * 4 + 255) / 256 * 256;
+                L.SB = StereoBuf{};
+                L.sampleRadR = nullptr;
+                if (stereo) {
+                    L.sampleRadR = (float*)p; p += (nPaths * 12 + 255) / 256 * 256;
+                    for (int q = 0; q < 6; q++) { L.SB.r[q] = (double*)p; p += (nPaths * 8 + 255) / 256 * 256; }
+                    for (int q = 0; q < 6; q++) { L.SB.g[q] = (uint32_t*)p; p += (nPaths * 4 + 255) / 256 * 256; }
+                }
             }
+            const StereoBuf SBnone{};
             const int nBounce = set.maxTraceDepth + 2;
-            for (int s0 = 0; s0 < spp; s0 += chunk) {
+            HIP_TRY(hipEventRecord(sc->evLaneStart, stream));               // the side lanes start after whatever precedes this frame on the caller's stream
+            for (int k = 1; k < nLanes; k++) HIP_TRY(hipStreamWaitEvent(sc->laneStream[k], sc->evLaneStart, 0));
+            int batch = 0;
+            for (int s0 = 0; s0 < spp; s0 += chunk, batch++) {
                 const int cn = std::min(chunk, spp - s0);
-                hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * cn + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
+                Lane& L = lane[batch % nLanes];
+                hipStream_t ls = L.stream;
+                hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * cn + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, ls, F, nItems, s0, cn, L.x397);
                 for (int eye = 0; eye < (stereo ? 2 : 1); eye++) {
                     // queue 0 is dense: one segment holding every slot of the batch
-                    hipLaunchKernelGGL(k_meta_dense, dim3(1), dim3(64), 0, stream, sc->d_qmeta, (uint32_t)((size_t)nItems * cn));
-                    float* rad = eye == 0 ? sampleRad : sampleRadR;
+                    hipLaunchKernelGGL(k_meta_dense, dim3(1), dim3(64), 0, ls, L.meta, (uint32_t)((size_t)nItems * cn));
+                    float* rad = eye == 0 ? L.sampleRad : L.sampleRadR;
                     // left pass of a stereo frame saves generator cursors at path end; mono and the right pass do not
-                    const StereoBuf& save = (stereo && eye == 0) ? SB : SBnone;
-                    hipLaunchKernelGGL(k_pt_init<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, C, F, nItems, s0, cn, Q[0],
-                                       rad, x397, SB, eye, sc->d_stats);
+                    const StereoBuf& save = (stereo && eye == 0) ? L.SB : SBnone;
+                    hipLaunchKernelGGL(k_pt_init<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, ls, S, C, F, nItems, s0, cn, L.Q[0],
+                                       rad, L.x397, L.SB, eye, sc->d_stats);
                     for (int b = 0; b < nBounce; b++) {
                         hipEvent_t ea = pool_event(sc, nTraceEvents), eb = pool_event(sc, nTraceEvents + 1);
-                        HIP_TRY(hipEventRecord(ea, stream));
-                        hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(bounce_grid((size_t)nItems * cn)), dim3(256), 0, stream, S, Q[b & 1], Q[(b + 1) & 1], SQ,
-                                           sc->d_qmeta + (b & 1), sc->d_qmeta + ((b + 1) & 1), sc->d_qmeta + 2, rad, save, sc->d_stats);
-                        HIP_TRY(hipEventRecord(eb, stream));
+                        HIP_TRY(hipEventRecord(ea, ls));
+                        hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(bounce_grid((size_t)nItems * cn)), dim3(256), 0, ls, S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ,
+                                           L.meta + (b & 1), L.meta + ((b + 1) & 1), L.meta + 2, rad, save, sc->d_stats);
+                        HIP_TRY(hipEventRecord(eb, ls));
                         nTraceEvents += 2;
-                        hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, stream, sc->d_qmeta + ((b + 1) & 1), sc->d_qmeta + 2);
+                        hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, ls, L.meta + ((b + 1) & 1), L.meta + 2);
                         hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
-                        HIP_TRY(hipEventRecord(ec, stream));
-                        hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, stream, S, SQ, sc->d_qmeta + 2, rad, sc->d_stats + 1);
-                        HIP_TRY(hipEventRecord(ed, stream));
+                        HIP_TRY(hipEventRecord(ec, ls));
+                        hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, ls, S, L.SQ, L.meta + 2, rad, sc->d_stats + 1);
+                        HIP_TRY(hipEventRecord(ed, ls));
                         nShadowEvents += 2;
                     }
                 }
-                hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, stream, F, C, set.saturation, nItems, s0, cn, sampleRad, sampleRadR, sum, d_rgb);
+                // the running per-pixel sum takes the batches in sample order
+                if (batch > 0 && nLanes > 1) HIP_TRY(hipStreamWaitEvent(ls, sc->evResolved[(batch - 1) % nLanes], 0));
+                hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, ls, F, C, set.saturation, nItems, s0, cn, L.sampleRad, L.sampleRadR, sum, d_rgb);
+                HIP_TRY(hipEventRecord(sc->evResolved[batch % nLanes], ls));
             }
+            // the last resolve follows every earlier one, and each resolve is the last launch of its batch
+            if (nLanes > 1) HIP_TRY(hipStreamWaitEvent(stream, sc->evResolved[(batch - 1) % nLanes], 0));
         }
     } else {
         set_error("frayhip_render: unknown mode");

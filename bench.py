@@ -284,6 +284,17 @@ def main():
                          "note": "algorithmic bytes per SURVEY 8(d); scene tables are L2/LDS resident, so this is not HBM traffic"},
             "kernel_ms_per_step": kernels_ms / args.steps,
         }
+        if shadow_launches and kernels_ms > 0:
+            # Path-tracing batches run on several streams at once, so the launches of different batches overlap and a
+            # launch's event-to-event duration includes the time it shared the chip (the durations sum to more than the
+            # frame).  `achieved` above is the contract's figure (bytes per launch / average launch duration, the same
+            # average rocprofv3 reports); this is the same byte count over the kernel's share of the frame's wall time.
+            share = trace_ms / (trace_ms + shadow_ms)
+            excl_ms = kernels_ms * share / max(1, trace_launches)
+            out["roofline"]["achieved_exclusive"] = bytes_per_launch / (excl_ms * 1e-3) / 1e9
+            out["roofline"]["avg_launch_ms_exclusive"] = excl_ms
+            out["roofline"]["concurrency_note"] = ("launches of up to 4 batches overlap on separate streams; *_exclusive = this kernel's "
+                                                   "share (by summed launch time) of the frame's wall time per launch")
         if shadow_launches:
             sb = st_counts["alg_bytes_shadow"] * args.steps / shadow_launches
             sms = shadow_ms / shadow_launches

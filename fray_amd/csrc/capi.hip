@@ -49,7 +49,7 @@ void putX(DXform& X, const frayhip_transform& T)
 }  // namespace
 
 #ifndef FRAY_PT_LANES
-#define FRAY_PT_LANES 3   // measured on the headline frame: 1 -> 150 ms, see DESIGN.md section 4
+#define FRAY_PT_LANES 4   // headline frame / smallpt 64 spp, ms: 1 lane 150.0 / 136.3, 2 -> 136.9 / 126.5, 3 -> 135.8 / 125.1, 4 -> 135.8 / 123.8, 6 -> 135.2 / 123.9
 #endif
 
 struct frayhip_scene {

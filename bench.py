@@ -293,7 +293,7 @@ def main():
             excl_ms = kernels_ms * share / max(1, trace_launches)
             out["roofline"]["achieved_exclusive"] = bytes_per_launch / (excl_ms * 1e-3) / 1e9
             out["roofline"]["avg_launch_ms_exclusive"] = excl_ms
-            out["roofline"]["concurrency_note"] = ("launches of up to 4 batches overlap on separate streams; *_exclusive = this kernel's "
+            out["roofline"]["concurrency_note"] = ("launches of up to 4 batches overlap on 4 streams; *_exclusive = this kernel's "
                                                    "share (by summed launch time) of the frame's wall time per launch")
         if shadow_launches:
             sb = st_counts["alg_bytes_shadow"] * args.steps / shadow_launches

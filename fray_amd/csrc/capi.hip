@@ -48,6 +48,9 @@ void putX(DXform& X, const frayhip_transform& T)
 
 }  // namespace
 
+#ifndef FRAY_PT_BUDGET_LOG2
+#define FRAY_PT_BUDGET_LOG2 28   // paths in flight over all lanes (240 B each); headline frame: 2^25 138.4, 2^26 135.3, 2^27 135.6, 2^28 133.6 ms
+#endif
 #ifndef FRAY_PT_LANES
 #define FRAY_PT_LANES 4   // headline frame / smallpt 64 spp, ms: 1 lane 150.0 / 136.3, 2 -> 136.9 / 126.5, 3 -> 135.8 / 125.1, 4 -> 135.8 / 123.8, 6 -> 135.2 / 123.9
 #endif
@@ -686,7 +689,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             // Batches of `chunk` samples per pixel; up to FRAY_PT_LANES batches are in flight at once, each on its own
             // stream with its own queues, so one batch's launch gaps, scans and kernel tails are filled by the others'
             // blocks.  Only the resolves are ordered (evResolved): the per-pixel sum runs in sample order.
-            const size_t budget = (size_t)1 << 26;                        // paths in flight over all lanes
+            const size_t budget = (size_t)1 << FRAY_PT_BUDGET_LOG2;       // paths in flight over all lanes
             int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / FRAY_PT_LANES / (size_t)nItems);
             if (chunk > spp) chunk = spp;
             if (f->spp_chunk <= 0 && spp >= 2 * FRAY_PT_LANES && chunk * FRAY_PT_LANES > spp) chunk = (spp + FRAY_PT_LANES - 1) / FRAY_PT_LANES;   // enough batches to fill the lanes

@@ -273,7 +273,9 @@ int  frayhip_render(frayhip_scene* s, const frayhip_frame* f,
                     float* rgb, int32_t* hit_id, double* hit_dist, frayhip_stats* st);
 /* Same, with DEVICE pointers (hipMalloc'ed by the caller, e.g. a torch tensor's data_ptr);
  * work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and the call
- * returns after the stream has been synchronised. */
+ * returns after the stream has been synchronised.  A path-traced frame also runs batches on
+ * streams of its own; they start after everything already enqueued on `hip_stream` and are
+ * joined back into it before the call returns, so the caller sees one stream's ordering. */
 int  frayhip_render_device(frayhip_scene* s, const frayhip_frame* f,
                            float* d_rgb, int32_t* d_hit_id, double* d_hit_dist,
                            void* hip_stream, frayhip_stats* st);

@@ -304,7 +304,9 @@ FD void path_load_rest(const PathQueue& Q, uint32_t i, PathState& s)
 // share, so it cannot overflow); it publishes one count.  A one-block scan turns the counts into
 // offsets, and a consumer lane maps its dense index to (segment, position) by a 13-step binary
 // search over the offsets held in LDS.
+#ifndef FRAY_MAXSEG
 #define FRAY_MAXSEG 8192   // = 2048 blocks x 4 waves, the largest grid grid_for() returns
+#endif
 struct QMeta {
     uint32_t n;        // live paths in the queue
     uint32_t chunk;    // capacity (and stride) of one segment

@@ -20,10 +20,19 @@ def random_mesh_obj(rng, n_tris, with_normals):
             lines.append("vn %.6f %.6f %.6f" % tuple(n))
         for v in verts:
             lines.append("vt %.4f %.4f" % (v[0] * 0.3 + 0.5, v[1] * 0.3 + 0.5))
+    seen = set()
     for _ in range(n_tris):
         a = int(rng.integers(nv))
         near = np.argsort(np.linalg.norm(verts - verts[a], axis=1))[1:6]
         b, c = rng.choice(near, 2, replace=False)
+        # No two faces over the same three vertices: coincident triangles of opposite orientation make the
+        # winner of "last equal distance wins" -- hence the sign of the normal the path tracer uses raw --
+        # a matter of the last bit of the ray direction, and the device's sin / cos / acos are not
+        # glibc's bit for bit (tests/scenes/fuzz1009, test_coincident_opposite_triangles below).
+        key = tuple(sorted((a, int(b), int(c))))
+        if key in seen:
+            continue
+        seen.add(key)
         if with_normals:
             lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d" % (a + 1, a + 1, a + 1, b + 1, b + 1, b + 1, c + 1, c + 1, c + 1))
         else:
@@ -33,9 +42,14 @@ def random_mesh_obj(rng, n_tris, with_normals):
 
 def random_scene(rng, tmp, gi):
     W, H = int(rng.integers(40, 90)), int(rng.integers(30, 70))
-    s = ["GlobalSettings {\n\tframeWidth %d\n\tframeHeight %d\n\tambientLight (0.15, 0.15, 0.2)\n\tmaxTraceDepth %d\n\twantAA off\n\tgi %d\n\tpathsPerPixel 3\n}" % (W, H, int(rng.integers(2, 5)), gi)]
+    s = ["GlobalSettings {\n\tframeWidth %d\n\tframeHeight %d\n\tambientLight (0.15, 0.15, 0.2)\n\tmaxTraceDepth %d\n\twantAA %s\n\tgi %d\n\tpathsPerPixel %d\n}" %
+         (W, H, int(rng.integers(2, 5)), "on" if (not gi and rng.random() < 0.3) else "off", gi, int(rng.choice([3, 9])))]   # 9 spp: four batches on four streams
     s.append("Camera camera {\n\tposition (%.3f, %.3f, -14)\n\tyaw %.2f\n\tpitch %.2f\n\troll %.2f\n\tfov %.1f\n\taspectRatio %.3f\n}" %
              (rng.normal() * 2, 3 + rng.normal(), rng.normal() * 8, -10 + rng.normal() * 5, rng.normal() * 5, 55 + rng.random() * 30, W / H))
+    if rng.random() < 0.35:      # thin lens and / or anaglyph stereo
+        s[-1] = s[-1][:-2] + "\n\tdof on\n\tnumSamples %d\n\tfNumber %.1f\n\tfocalPlaneDist 14\n}" % (int(rng.integers(2, 5)), 2 + rng.random() * 6)
+    if rng.random() < 0.25:
+        s[-1] = s[-1][:-2] + "\n\tstereoSeparation %.2f\n}" % (0.1 + rng.random() * 0.3)
     s.append("RectLight l1 {\n\ttranslate (%.2f, 12, %.2f)\n\tscale (5, 5, 5)\n\trotate (%.1f, 0, %.1f)\n\tpower 40\n\txSubd 2\n\tySubd 2\n}" % (rng.normal() * 2, rng.normal() * 2, rng.normal() * 10, rng.normal() * 10))
     if rng.random() < 0.5:
         s.append("PointLight l2 {\n\tpos (%.2f, 9, -6)\n\tpower 60\n\tcolor (0.9, 0.8, 0.7)\n}" % (rng.normal() * 4))
@@ -45,6 +59,8 @@ def random_scene(rng, tmp, gi):
     s.append("Cube box2 {\n\thalfSide 1.0\n\tO (0.7, 0.6, 0.5)\n}")
     s.append("CsgMinus carved {\n\tleft box\n\tright ball\n}")
     s.append("CsgAnd lens {\n\tleft ball\n\tright box2\n}")
+    s.append("CsgPlus both {\n\tleft carved\n\tright lens\n}")            # CsgOp of CsgOps
+    s.append("CsgMinus deep {\n\tleft both\n\tright box2\n}")             # three levels
     (tmp / "m1.obj").write_text(random_mesh_obj(rng, int(rng.integers(30, 120)), True))
     (tmp / "m2.obj").write_text(random_mesh_obj(rng, int(rng.integers(4, 18)), False))
     s.append('Mesh blob {\n\tfile "m1.obj"\n\tbackfaceCulling %s\n}' % ("false" if rng.random() < 0.5 else "true"))
@@ -55,20 +71,21 @@ def random_scene(rng, tmp, gi):
     s.append("Phong ph {\n\tcolor (0.8, 0.3, 0.2)\n\tspecularExponent %.0f\n}" % (10 + rng.random() * 80))
     s.append("Refl mir {\n\tmultiplier 0.85\n}")
     s.append("Refr glass {\n\tior 1.4\n\tmultiplier 0.9\n}")
-    shaders = ["lam", "grey", "ph", "mir", "glass"] if not gi else ["lam", "grey", "mir", "glass"]
-    geoms = ["ball", "box", "carved", "lens", "blob", "shard"]
+    s.append("Layered coat {\n\tlayer grey (1, 1, 1)\n\tlayer mir (0.25, 0.25, 0.25)\n}")
+    shaders = ["lam", "grey", "ph", "mir", "glass", "coat"] if not gi else ["lam", "grey", "mir", "glass"]
+    geoms = ["ball", "box", "carved", "lens", "blob", "shard", "both", "deep"]
     s.append("Node floorNode {\n\tgeometry floor\n\tshader lam\n}")
     for i, g in enumerate(geoms):
         sh = shaders[int(rng.integers(len(shaders)))]
         sc = 0.6 + rng.random() * 1.2
         s.append("Node n%d {\n\tgeometry %s\n\tshader %s\n\tscale (%.3f, %.3f, %.3f)\n\trotate (%.1f, %.1f, %.1f)\n\ttranslate (%.2f, %.2f, %.2f)\n}" %
                  (i, g, sh, sc, sc * (0.7 + rng.random() * 0.6), sc, rng.random() * 360, rng.normal() * 20, rng.normal() * 20,
-                  (i - 2.5) * 2.6 + rng.normal() * 0.3, rng.random() * 2, rng.normal() * 1.5))
+                  (i - 3.5) * 2.4 + rng.normal() * 0.3, rng.random() * 2, rng.normal() * 1.5))
     (tmp / "scene.fray").write_text("\n".join(s) + "\n")
     return str(tmp / "scene.fray")
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(14))
 def test_random_scene_parity(fray, abi, oracle, gpu, tmp_path, seed):
     rng = np.random.default_rng(1000 + seed)
     gi = seed % 2
@@ -88,3 +105,56 @@ def test_random_scene_parity(fray, abi, oracle, gpu, tmp_path, seed):
     r = np.sqrt(((img.astype(np.float64) - ref) ** 2).mean(axis=(0, 1)))
     assert np.all(r <= 1e-4), r
     s.close()
+
+
+def test_coincident_opposite_triangles(fray, abi, oracle, gpu, tmp_path):
+    """tests/scenes/fuzz1009: the mesh `shard` holds the same triangle twice with opposite orientation and
+    no back-face culling.  Both copies are hit at distances that differ in the last bits at most, so which
+    one wins -- and with it the sign of the raw normal that Lambert::eval / spawnRay use -- follows the last
+    bit of the ray direction.  Camera rays are computed identically on both sides: hit records and the
+    first bounce agree bit for bit.  Directions of later bounces come out of sin / cos / acos, where the
+    device's libm and glibc differ in the last place now and then, so a handful of paths that meet the
+    twin triangles again take the other normal.  The oracle equals the reference's own code on this scene
+    (tests/golden/ref_fuzz1009_pt.npz); the device must differ in those few pixels only, and not at all once
+    the twin is removed or culled."""
+    import shutil
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenes", "fuzz1009")
+
+    def render(edit=None, **over):
+        d = tmp_path / ("v%d" % len(os.listdir(tmp_path)))
+        shutil.copytree(src, d)
+        if edit:
+            edit(d)
+        s = fray.Scene.parseScene(str(d / "scene.fray"))
+        s.settings.numPaths = 8
+        for k, v in over.items():
+            setattr(s.settings, k, v)
+        s.beginRender()
+        ids, dist, _ = s.primary_hits()
+        oi, od, _ = oracle.render(s.desc, abi.MODE_PRIMARY_ID)
+        assert np.array_equal(ids, oi) and np.array_equal(dist, od)
+        img, _ = s.render(seed=9)
+        ref, _ = oracle.render(s.desc, abi.MODE_RENDER, seed=9)
+        s.close()
+        diff = np.abs(img.astype(np.float64) - ref)
+        return ids, diff
+
+    ids, diff = render()
+    bad = (diff > 1e-5).any(axis=2)
+    shard = 6                                              # floorNode, n0..n4, then n5 = shard
+    assert bad.sum() <= 12 and np.all(ids[bad] == shard), (int(bad.sum()), np.unique(ids[bad]))
+    assert np.sqrt((diff[~bad] ** 2).mean()) <= 1e-6
+    ids, diff = render(maxTraceDepth=0)                    # camera ray + its next-event sample: no libm in the directions
+    assert np.sqrt((diff ** 2).mean()) <= 1e-6
+
+    def drop_twin(d):
+        p = d / "m2.obj"
+        p.write_text(p.read_text().replace("f 5 1 2\n", ""))
+    ids, diff = render(drop_twin)
+    assert np.all(np.sqrt((diff ** 2).mean(axis=(0, 1))) <= 1e-4)
+
+    def cull(d):
+        p = d / "scene.fray"
+        p.write_text(p.read_text().replace('file "m2.obj"\n\tbackfaceCulling false', 'file "m2.obj"\n\tbackfaceCulling true'))
+    ids, diff = render(cull)
+    assert np.all(np.sqrt((diff ** 2).mean(axis=(0, 1))) <= 1e-4)

@@ -40,6 +40,25 @@ def random_mesh_obj(rng, n_tris, with_normals):
     return "\n".join(lines) + "\n"
 
 
+def write_bmp(path, rgb):
+    """24-bit uncompressed BMP, bottom-up rows padded to 4 bytes (what bitmap.cpp:117-195 reads)."""
+    import struct
+    h, w, _ = rgb.shape
+    row = (w * 3 + 3) // 4 * 4
+    data = bytearray()
+    for y in range(h - 1, -1, -1):
+        line = bytearray()
+        for x in range(w):
+            r, g, b = (int(v) for v in rgb[y, x])
+            line += bytes((b, g, r))
+        line += b"\0" * (row - w * 3)
+        data += line
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", 54 + len(data), 0, 0, 54))
+        f.write(struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, len(data), 2835, 2835, 0, 0))
+        f.write(data)
+
+
 def random_scene(rng, tmp, gi):
     W, H = int(rng.integers(40, 90)), int(rng.integers(30, 70))
     s = ["GlobalSettings {\n\tframeWidth %d\n\tframeHeight %d\n\tambientLight (0.15, 0.15, 0.2)\n\tmaxTraceDepth %d\n\twantAA %s\n\tgi %d\n\tpathsPerPixel %d\n}" %
@@ -72,20 +91,30 @@ def random_scene(rng, tmp, gi):
     s.append("Refl mir {\n\tmultiplier 0.85\n}")
     s.append("Refr glass {\n\tior 1.4\n\tmultiplier 0.9\n}")
     s.append("Layered coat {\n\tlayer grey (1, 1, 1)\n\tlayer mir (0.25, 0.25, 0.25)\n}")
-    shaders = ["lam", "grey", "ph", "mir", "glass", "coat"] if not gi else ["lam", "grey", "mir", "glass"]
+    write_bmp(tmp / "tex.bmp", rng.integers(0, 256, size=(int(rng.integers(3, 9)), int(rng.integers(3, 9)), 3)))
+    write_bmp(tmp / "bump.bmp", rng.integers(0, 256, size=(8, 8, 3)))
+    s.append('BitmapTexture pic {\n\tfile "tex.bmp"\n\tscaling %.2f\n}' % (0.5 + rng.random() * 3))
+    s.append('BumpTexture dents {\n\tfile "bump.bmp"\n\tstrength %.2f\n\tscaling %.2f\n}' % (0.5 + rng.random() * 4, 0.5 + rng.random() * 2))
+    s.append("Lambert painted {\n\ttexture pic\n}")
+    s.append("Fresnel fres {\n\tior 1.45\n}")
+    s.append("Layered wet {\n\tlayer painted (1, 1, 1)\n\tlayer mir (1, 1, 1) fres\n}")
+    s.append("Refl rough {\n\tglossiness %.2f\n\tnumSamples 3\n\tmultiplier 0.8\n}" % (0.75 + rng.random() * 0.2))
+    s.append("Const flat {\n\tcolor (0.2, 0.9, 0.4)\n}")
+    shaders = ["lam", "grey", "ph", "mir", "glass", "coat", "painted", "wet", "rough", "flat"] if not gi else ["lam", "grey", "mir", "glass", "painted"]
     geoms = ["ball", "box", "carved", "lens", "blob", "shard", "both", "deep"]
     s.append("Node floorNode {\n\tgeometry floor\n\tshader lam\n}")
     for i, g in enumerate(geoms):
         sh = shaders[int(rng.integers(len(shaders)))]
         sc = 0.6 + rng.random() * 1.2
-        s.append("Node n%d {\n\tgeometry %s\n\tshader %s\n\tscale (%.3f, %.3f, %.3f)\n\trotate (%.1f, %.1f, %.1f)\n\ttranslate (%.2f, %.2f, %.2f)\n}" %
-                 (i, g, sh, sc, sc * (0.7 + rng.random() * 0.6), sc, rng.random() * 360, rng.normal() * 20, rng.normal() * 20,
+        bump = "\n\tbump dents" if (g in ("ball", "blob", "box") and rng.random() < 0.4) else ""
+        s.append("Node n%d {\n\tgeometry %s\n\tshader %s%s\n\tscale (%.3f, %.3f, %.3f)\n\trotate (%.1f, %.1f, %.1f)\n\ttranslate (%.2f, %.2f, %.2f)\n}" %
+                 (i, g, sh, bump, sc, sc * (0.7 + rng.random() * 0.6), sc, rng.random() * 360, rng.normal() * 20, rng.normal() * 20,
                   (i - 3.5) * 2.4 + rng.normal() * 0.3, rng.random() * 2, rng.normal() * 1.5))
     (tmp / "scene.fray").write_text("\n".join(s) + "\n")
     return str(tmp / "scene.fray")
 
 
-@pytest.mark.parametrize("seed", range(14))
+@pytest.mark.parametrize("seed", range(20))
 def test_random_scene_parity(fray, abi, oracle, gpu, tmp_path, seed):
     rng = np.random.default_rng(1000 + seed)
     gi = seed % 2

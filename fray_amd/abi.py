@@ -168,6 +168,7 @@ SYMBOLS = {
     "frayhip_to_rgb32": (C.c_int, [VP, VP, C.c_int]),
     "frayhip_save_bmp": (C.c_int, [C.c_char_p, VP, C.c_int, C.c_int]),
     "frayhip_debug_rng": (C.c_int, [u32, C.c_int, VP, VP, VP, C.c_int]),
+    "frayhip_debug_libm": (C.c_int, [C.c_int, VP, VP, VP, VP, VP]),
     "frayhip_last_error": (C.c_char_p, []),
     "frayhip_abi_version": (C.c_int, []),
     "frayhip_sizeof": (C.c_int, [C.c_char_p]),

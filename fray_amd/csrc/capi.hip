@@ -893,6 +893,40 @@ int frayhip_debug_rng(uint32_t seed, int n, float* floats, double* doubles, int3
     return FRAYHIP_OK;
 }
 
+__global__ void k_debug_libm(int n, const double* x, double* out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double sn, cs;
+        sincos(x[i], &sn, &cs);
+        out[i] = sn;
+        out[n + i] = cs;
+        double a = x[i];
+        a = a - 2.0 * floor(a * 0.5) - 1.0;                 // folded into [-1, 1) for acos
+        out[2 * n + i] = acos(a);
+        out[3 * n + i] = a;
+    }
+}
+
+int frayhip_debug_libm(int n, const double* x, double* sin_out, double* cos_out, double* acos_out, double* acos_arg)
+{
+    if (n <= 0 || n > (1 << 22) || !x) { set_error("frayhip_debug_libm: bad argument"); return FRAYHIP_E_ARG; }
+    double *dx = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void**)&dx, (size_t)n * 8));
+    if (hipMalloc((void**)&dout, (size_t)n * 32) != hipSuccess) { (void)hipFree(dx); set_error("frayhip_debug_libm: out of device memory"); return FRAYHIP_E_NOMEM; }
+    int rc = FRAYHIP_OK;
+    if (hipMemcpy(dx, x, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) rc = FRAYHIP_E_NODEVICE;
+    if (rc == FRAYHIP_OK) {
+        hipLaunchKernelGGL(k_debug_libm, dim3(grid_for(n)), dim3(256), 0, nullptr, n, dx, dout);
+        if (hipDeviceSynchronize() != hipSuccess) rc = FRAYHIP_E_NODEVICE;
+    }
+    double* outs[4] = {sin_out, cos_out, acos_out, acos_arg};
+    for (int k = 0; k < 4 && rc == FRAYHIP_OK; k++)
+        if (outs[k] && hipMemcpy(outs[k], dout + (size_t)k * n, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = FRAYHIP_E_NODEVICE;
+    (void)hipFree(dx); (void)hipFree(dout);
+    if (rc != FRAYHIP_OK) set_error("frayhip_debug_libm: device error");
+    return rc;
+}
+
 static int pack_impl(const float* d_frame, float* d_packed, int width, int height, int channels, int first, int stride, void* hip_stream, int unpack)
 {
     if (!d_frame || !d_packed || channels < 1) { set_error("frayhip_pack_buckets_device: bad argument"); return FRAYHIP_E_ARG; }

@@ -304,6 +304,13 @@ int  frayhip_save_bmp(const char* path, const float* rgb, int width, int height)
  * generator's 227-word register window and two full state twists). */
 int  frayhip_debug_rng(uint32_t seed, int n, float* floats, double* doubles, int32_t* ints, int int_hi);
 
+/* Test hook: the device's sincos(x[i]) and acos(fold(x[i])) -- the libm calls behind
+ * hemisphereSample / unitDiscSample (main.cpp:92-116, random_generator.cpp:71-80), which the
+ * reference takes from glibc -- so that a test can state how far the two libms are apart.
+ * fold(x) = x - 2*floor(x/2) - 1 in [-1, 1) is returned in acos_arg.  Host buffers of n doubles,
+ * any output may be NULL. */
+int  frayhip_debug_libm(int n, const double* x, double* sin_out, double* cos_out, double* acos_out, double* acos_arg);
+
 const char* frayhip_last_error(void);
 int  frayhip_abi_version(void);
 /* sizeof() of a struct of this header by name ("frayhip_mesh", ...), -1 if unknown: lets a

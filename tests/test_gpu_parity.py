@@ -566,3 +566,30 @@ def test_cxx_host_example_renders_like_the_python_path(fray, gpu, tmp_path):
     assert fray.lib.frayhip_save_bmp(str(ref).encode(), img.ctypes.data, 64, 48) == 0
     assert open(out, "rb").read() == open(ref, "rb").read()
     s.close()
+
+
+def test_device_libm_vs_glibc(fray, gpu):
+    """sin / cos / acos are the reference's third-party arithmetic (glibc); the device has ROCm's.  They must
+    agree to the last place or two -- which is what keeps colour parity at ~1e-8 -- and this states how often
+    they agree exactly on the arguments the samplers produce (theta in [0, 2 pi), 2v-1 in [-1, 1))."""
+    import math
+    rng = np.random.default_rng(7)
+    n = 1 << 16
+    x = rng.random(n) * 2 * np.pi
+    sn, cs, ac, arg = (np.zeros(n) for _ in range(4))
+    assert fray.lib.frayhip_debug_libm(n, x.ctypes.data, sn.ctypes.data, cs.ctypes.data, ac.ctypes.data, arg.ctypes.data) == 0
+    ref_arg = x - 2.0 * np.floor(x * 0.5) - 1.0
+    assert np.array_equal(arg, ref_arg)
+
+    def ulps(a, b):
+        return np.abs(a.view(np.int64) - b.view(np.int64))
+    # math.* calls the C library (glibc here, as in the reference build); numpy's vector loops are not glibc
+    glibc = lambda f, v: np.array([f(t) for t in v.tolist()])
+    for name, got, want in (("sin", sn, glibc(math.sin, x)), ("cos", cs, glibc(math.cos, x)), ("acos", ac, glibc(math.acos, arg))):
+        u = ulps(got, want)
+        near_zero = np.abs(want) < 1e-3                     # ulps of a tiny result say little; compare absolutely there
+        assert u[~near_zero].max() <= 2, (name, int(u[~near_zero].max()))
+        assert np.abs(got - want)[near_zero].max(initial=0.0) <= 1e-18, name
+        exact = float((u == 0).mean())
+        print("%s: identical to glibc in %.2f %% of %d calls, max %d ulp" % (name, 100 * exact, n, int(u[~near_zero].max())))
+        assert exact > 0.5, (name, exact)

@@ -60,7 +60,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0):
+def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0, gpu_frame=None):
     """The oracle (a scalar C++ port of the reference path) timed on this box's host cores on a
     bounded sample of the same workload: every `stride`-th 48x48 bucket of the same frame."""
     from oracle.oracle import Oracle
@@ -79,8 +79,20 @@ def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0):
     want = int(max(threads, min(nb, target_seconds / per_bucket)))
     stride = max(1, nb // want)
     t0 = time.time()
-    _, st = orc.render(s.desc, mode, seed=seed, bucket_first=0, bucket_stride=stride, threads=threads)
+    cpu_img, st = orc.render(s.desc, mode, seed=seed, bucket_first=0, bucket_stride=stride, threads=threads)
     dt = time.time() - t0
+    parity = None
+    if gpu_frame is not None:
+        # the buckets the oracle just rendered, against the same pixels of the frame the GPU was timed on
+        import numpy as np
+        BW = (W - 1) // 48 + 1
+        mask = np.zeros((H, W), bool)
+        for b in range(0, nb, stride):
+            by, bx = divmod(b, BW)
+            mask[by * 48:by * 48 + 48, bx * 48:bx * 48 + 48] = True
+        d = gpu_frame[mask].astype(np.float64) - cpu_img[mask]
+        parity = {"pixels": int(mask.sum()), "rms_per_channel": [float(v) for v in np.sqrt((d ** 2).mean(axis=0))],
+                  "max_abs": float(np.abs(d).max()), "tolerance": 1e-4}
     rays = st["closest_rays"] + st["shadow_rays"]
     n_b = len(range(0, nb, stride))
     # single-thread figure on a smaller sample (~4 s)
@@ -90,7 +102,7 @@ def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0):
     dt1 = max(time.time() - t0, 1e-6)
     s.close()
     ref_cmp = reference_object_code_rate(fray_amd, abi, orc, wl, seed)
-    return {**({"reference_object_code": ref_cmp} if ref_cmp else {}),
+    return {**({"reference_object_code": ref_cmp} if ref_cmp else {}), **({"gpu_frame_vs_oracle_on_the_sample": parity} if parity else {}),
             "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": "%d of %d buckets (every %d-th 48x48 bucket) of the same frame, all spp, %.1f s, %d threads" % (n_b, nb, stride, dt, threads),
             "frame_ms_extrapolated": dt * 1e3 * nb / n_b,
@@ -343,7 +355,7 @@ def main():
             except (KeyError, ValueError):
                 pass
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(fray_amd, abi, wl, args.seed) if mode == abi.MODE_RENDER else None
+            out["cpu_baseline"] = cpu_baseline(fray_amd, abi, wl, args.seed, gpu_frame=frame.cpu().numpy()) if mode == abi.MODE_RENDER else None
         print(json.dumps(out), flush=True)
     scene.close()
     if world > 1:

@@ -202,6 +202,9 @@ def main():
     lib = fray_amd.lib
     from fray_amd import tiles
     gatherer = tiles.TileGather(W, H, 3, rank, world, dev, dist, stage_host=(args.backend != "nccl")) if world > 1 else None
+    # hit-record frames gather the same way: int32 ids as one 4-byte channel, f64 distances as two
+    gather_ids = tiles.TileGather(W, H, 1, rank, world, dev, dist, stage_host=(args.backend != "nccl")) if world > 1 and ids is not None else None
+    gather_dist = tiles.TileGather(W, H, 2, rank, world, dev, dist, stage_host=(args.backend != "nccl")) if world > 1 and ids is not None else None
     rdev = dev if args.backend == "nccl" else torch.device("cpu")     # where small reduction tensors live
 
     def stream_ptr():
@@ -215,6 +218,9 @@ def main():
         if world > 1 and mode == abi.MODE_RENDER:
             # the one exchange step: packed buckets -> rank 0 (peer-to-root sends over xGMI), then untile
             gatherer.gather(frame)
+        elif world > 1:
+            gather_ids.gather(ids.view(torch.float32).view(H, W, 1))          # bit patterns travel unchanged
+            gather_dist.gather(dists.view(torch.float32).view(H, W, 2))
         return st
 
     # counters + algorithmic bytes of one frame (instrumented kernels, untimed)
@@ -254,6 +260,15 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
 
     check = None
+    if args.check and world > 1 and mode == abi.MODE_PRIMARY_ID:
+        step()
+        if rank == 0:
+            wi, wd = torch.zeros_like(ids), torch.zeros_like(dists)
+            scene.render_device(frame.data_ptr(), seed=args.seed, bucket_first=0, bucket_stride=1, stream=stream_ptr(), mode=mode,
+                                d_id_ptr=wi.data_ptr(), d_dist_ptr=wd.data_ptr())
+            torch.cuda.synchronize()
+            check = bool(torch.equal(wi, ids) and torch.equal(wd, dists))
+        dist.barrier()
     if args.check and world > 1 and mode == abi.MODE_RENDER:
         step()
         if rank == 0:

@@ -2,12 +2,16 @@
 //
 //   k_primary      camera ray through integer (x, y) + closest hit          (MODE_PRIMARY_ID)
 //   k_whitted      raytrace() per pixel, samples looped in order             (MODE_RENDER, gi off)
-//   k_pt_init      path-tracing batch: seeds, pixel jitter, camera rays -> path queue
+//                  -- both as persistent waves claiming 8x8 pixel tiles (claim_items)
+//   k_seed         x[397] of the mt19937 seeding recurrence per (pixel, sample)
+//   k_pt_init      path-tracing batch: generator cursors, pixel jitter, camera rays -> dense path queue
 //   k_pt_bounce    one pathtrace() iteration for every live path: closest hit, bump, discarded
-//                  spawn, next-event estimation with its shadow ray, real spawn; survivors are
-//                  compacted into the next queue with a wave ballot + one atomic per wave
+//                  spawn, next-event sample (-> shadow queue), real spawn; survivors go to the wave's
+//                  own segment of the next queue (ballot rank, no global counter)
+//   k_scan         per-wave survivor counts -> segment offsets (path queue and shadow queue)
+//   k_pt_shadow    visible() for every queued next-event segment, radiance added to its sample
 //   k_pt_resolve   per pixel, samples summed in sample order (the reference's FP32 order)
-//   k_pack/unpack  bucket-major <-> row-major copies for the multi-GPU gather
+//   k_pack         bucket-major <-> row-major copies for the multi-GPU gather
 #pragma once
 #include "dev_shade.hpp"
 #include "dev_whitted.hpp"

@@ -1,6 +1,7 @@
 # Build recipe for the HIP renderer (fray_amd/libfrayhip.so), the CPU oracle
 # (oracle/libfray_oracle.so) and, when /root/reference is present, the partial reference build
 # (oracle/_ref/libfray_ref.so).  __graft_entry__.build() runs `make all`.
+MAKEFLAGS += -r
 HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 ARCH    ?= gfx950
@@ -12,8 +13,10 @@ CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off $(INC)
 
 HOST_SRC := fray_amd/csrc/host_scene.cpp fray_amd/csrc/host_loaders.cpp fray_amd/csrc/host_exr.cpp fray_amd/csrc/capi_host.cpp
 HOST_OBJ := $(HOST_SRC:.cpp=.o)
-HIP_SRC  := fray_amd/csrc/capi.hip
-HIP_OBJ  := $(HIP_SRC:.hip=.o)
+# render_variant.hip is compiled once per kernel flag word (render_impl<0..3>): four independent translation
+# units that `make -j` builds side by side
+VARIANT_OBJ := $(foreach st,0 1 2 3,fray_amd/csrc/variant$(st).o)
+HIP_OBJ  := fray_amd/csrc/capi.o $(VARIANT_OBJ)
 HIP_HDR  := $(wildcard fray_amd/csrc/*.h) $(wildcard fray_amd/csrc/*.hpp) include/frayhip.h
 
 all: fray_amd/libfrayhip.so oracle/libfray_oracle.so examples/fray_render ref
@@ -23,6 +26,11 @@ fray_amd/csrc/%.o: fray_amd/csrc/%.cpp $(HIP_HDR)
 
 fray_amd/csrc/%.o: fray_amd/csrc/%.hip $(HIP_HDR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+# -Rpass-analysis=kernel-resource-usage: registers, spills, scratch and LDS of every kernel of the variant (kept
+# next to the object; `make resources` gathers them into profiles/)
+fray_amd/csrc/variant%.o: fray_amd/csrc/render_variant.hip $(HIP_HDR)
+	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -DFRAY_ST=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> fray_amd/csrc/variant$*.resources.txt || (cat fray_amd/csrc/variant$*.resources.txt; false)
 
 fray_amd/libfrayhip.so: $(HOST_OBJ) $(HIP_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
@@ -38,8 +46,11 @@ examples/fray_render: examples/fray_render.cpp include/frayhip.h fray_amd/libfra
 ref:
 	@if [ -d /root/reference/src ]; then $(MAKE) -C oracle -f Makefile.ref; else echo "reference tree absent: oracle/_ref not rebuilt"; fi
 
+resources: $(VARIANT_OBJ)
+	python3 tools/kernel_resources.py fray_amd/csrc/variant*.resources.txt
+
 clean:
-	rm -f fray_amd/csrc/*.o fray_amd/libfrayhip.so oracle/libfray_oracle.so examples/fray_render
+	rm -f fray_amd/csrc/*.o fray_amd/csrc/*.resources.txt fray_amd/libfrayhip.so oracle/libfray_oracle.so examples/fray_render
 	rm -rf oracle/_ref
 
-.PHONY: all ref clean
+.PHONY: all ref clean resources

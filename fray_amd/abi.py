@@ -10,7 +10,7 @@ P = C.POINTER
 
 ABI_VERSION = 1
 
-OK, E_ARG, E_PARSE, E_NODEVICE, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5
+OK, E_ARG, E_PARSE, E_NODEVICE, E_UNSUPPORTED, E_NOMEM, E_HIP = 0, -1, -2, -3, -4, -5, -6
 GEOM_PLANE, GEOM_SPHERE, GEOM_CUBE, GEOM_MESH, GEOM_CSG = range(5)
 TEX_CHECKER, TEX_BITMAP, TEX_BUMP, TEX_FRESNEL = range(4)
 SHADER_CONST, SHADER_LAMBERT, SHADER_PHONG, SHADER_REFL, SHADER_REFR, SHADER_LAYERED = range(6)

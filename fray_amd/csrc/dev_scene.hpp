@@ -25,6 +25,12 @@
 #define FRAY_RO
 #endif
 
+// Envelope of the device CSG code (dev_trace.hpp csg_intersect); frayhip_scene_create checks scenes against it.
+#define FRAY_CSG_MAX 16   // intersections kept per operand (the reference keeps up to 30)
+#ifndef FRAY_CSG_DEPTH
+#define FRAY_CSG_DEPTH 3  // CsgOp levels: 1 = operands are plain geometries, 3 = a CSG of CSGs of CSGs (deeper scenes are rejected at upload)
+#endif
+
 struct DXform { double off[3]; double m[9]; double inv[9]; };
 
 struct DNode {

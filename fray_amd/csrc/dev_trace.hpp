@@ -323,10 +323,6 @@ FD bool prim_intersect(const DScene& S, int kind, int index, V3 s, V3 d, V3 rd, 
     return true;
 }
 
-#define FRAY_CSG_MAX 16   // intersections kept per operand (the reference keeps up to 30)
-#ifndef FRAY_CSG_DEPTH
-#define FRAY_CSG_DEPTH 3  // CsgOp levels: 1 = operands are plain geometries, 3 = a CSG of CSGs of CSGs (deeper scenes are rejected at upload)
-#endif
 
 template <int ST, int LEVELS>
 FD bool csg_intersect(const DScene& S, const FRAY_RO DCsg& G, V3 s, V3 d, V3 rd, GHit& win, bool& envelope, Cnt& c);

@@ -15,6 +15,7 @@
 #pragma once
 #include "dev_shade.hpp"
 #include "dev_whitted.hpp"
+#include "dev_queues.hpp"
 
 #ifndef FRAY_PRIMARY_WAVES
 #define FRAY_PRIMARY_WAVES 5
@@ -43,17 +44,6 @@ FD bool item_pixel(const DFrame& F, int item, int& x, int& y)
     y = by * 48 + (tile / 6) * 8 + (in >> 3);
     return x < F.W && y < F.H;
 }
-// the packed (gather) layout: bucket-major, rows of 48 pixels inside a bucket (include/frayhip.h)
-FD bool packed_pixel(const DFrame& F, int item, int& x, int& y)
-{
-    int k = item / 2304, local = item - k * 2304;
-    int b = F.bucketFirst + k * F.bucketStride;
-    int bx = b % F.BW, by = b / F.BW;
-    x = bx * 48 + local % 48;
-    y = by * 48 + local / 48;
-    return x < F.W && y < F.H;
-}
-
 // Persistent waves.  The work items of a frame form nItems / 64 tiles (one 8x8 pixel tile = one wave's
 // worth; nItems is a multiple of 2304, hence of 64), split into 8 contiguous ranges with one cursor
 // each (DCursors: one 128-byte line per cursor, zeroed by the host with the counters).  A wave claims
@@ -120,7 +110,7 @@ FD void dof_ray(const DCamera& C, double x, double y, G& tab, V3& o, V3& d, int 
 #ifndef FRAY_SEED_CHAINS
 #define FRAY_SEED_CHAINS 4   // 4 and 8 measure the same (1.73 ms per 44 M seeds): the kernel is bound by v_mul_lo_u32 issue, not latency
 #endif
-__global__ __launch_bounds__(256) void k_seed(DFrame F, int nItems, int s0, int chunk, uint32_t* __restrict__ x397)
+static __global__ __launch_bounds__(256) void k_seed(DFrame F, int nItems, int s0, int chunk, uint32_t* __restrict__ x397)
 {
     constexpr int NC = FRAY_SEED_CHAINS;
     const uint32_t total = (uint32_t)nItems * (uint32_t)chunk;
@@ -151,7 +141,7 @@ __global__ __launch_bounds__(256) void k_seed(DFrame F, int nItems, int s0, int 
 
 // ---- MODE_PRIMARY_ID ------------------------------------------------------------------------------
 template <int ST>
-__global__ __launch_bounds__(256, FRAY_PRIMARY_WAVES) void k_primary(DScene S, DCamera C, DFrame F, int nItems, int32_t* __restrict__ hitId,
+static __global__ __launch_bounds__(256, FRAY_PRIMARY_WAVES) void k_primary(DScene S, DCamera C, DFrame F, int nItems, int32_t* __restrict__ hitId,
                                                  double* __restrict__ hitDist, DStats* st, DCursors* cur)
 {
     Cnt c = zero_cnt();
@@ -187,10 +177,10 @@ FD C3 raytrace_flat(const DScene& S, V3 o, V3 d, G& tab, Cnt& c)
     return shade_direct<ST, G>(S, sh, d, info, tab, sh.kind == 2, c);   // Lambert / Phong
 }
 
-__constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0, 0.6}, {0.6, 0.6}};   // main.cpp:55-61
+static __constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0, 0.6}, {0.6, 0.6}};   // main.cpp:55-61
 
 template <int ST, bool REC>
-__global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(DScene S, DCamera C, DFrame F, int nItems, float* __restrict__ rgb, uint32_t* mtWork,
+static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(DScene S, DCamera C, DFrame F, int nItems, float* __restrict__ rgb, uint32_t* mtWork,
                                                  const uint32_t* __restrict__ x397, DStats* st, DCursors* cur)
 {
     Cnt c = zero_cnt();
@@ -245,24 +235,6 @@ __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(DScene S, D
 // Path state, structure of arrays (one lane = one path, consecutive lanes = consecutive entries,
 // so every array is read and written fully coalesced).  80 bytes per path; radiance is accumulated in
 // the per-sample buffer (sampleRad[slot]), in bounce order, by k_pt_shadow and at termination.
-struct PathQueue {
-    double* ox; double* oy; double* oz;
-    double* dx; double* dy; double* dz;
-    float* tr; float* tg; float* tb;      // pathMultiplier
-    uint32_t* slot;                       // sample-major slot in the batch
-    uint32_t* depthFlags;                 // depth | flags << 16
-    uint32_t* rndJ; uint32_t* rndA; uint32_t* rndB;
-    uint32_t* tabJ; uint32_t* tabA; uint32_t* tabB;
-};
-
-// Shadow (next-event) queue: segment a->b, the radiance to add if it is unobstructed, the sample slot.
-struct ShadowQueue {
-    double* ax; double* ay; double* az;
-    double* bx; double* by; double* bz;
-    float* cr; float* cg; float* cb;
-    uint32_t* slot;
-};
-
 struct PathState {
     V3 o, d;
     C3 pm;
@@ -308,19 +280,7 @@ FD void path_load_rest(const PathQueue& Q, uint32_t i, PathState& s)
 // share, so it cannot overflow); it publishes one count.  A one-block scan turns the counts into
 // offsets, and a consumer lane maps its dense index to (segment, position) by a 13-step binary
 // search over the offsets held in LDS.
-#ifndef FRAY_MAXSEG
-#define FRAY_MAXSEG 8192   // = 2048 blocks x 4 waves, the largest grid grid_for() returns
-#endif
-struct QMeta {
-    uint32_t n;        // live paths in the queue
-    uint32_t chunk;    // capacity (and stride) of one segment
-    uint32_t nSeg;
-    uint32_t pad;
-    uint32_t cnt[FRAY_MAXSEG];
-    uint32_t off[FRAY_MAXSEG + 1];
-};
-
-__global__ __launch_bounds__(1024) void k_scan(QMeta* m0, QMeta* m1)
+static __global__ __launch_bounds__(1024) void k_scan(QMeta* m0, QMeta* m1)
 {
     QMeta* m = blockIdx.x == 0 ? m0 : m1;
     __shared__ uint32_t part[1024];
@@ -344,7 +304,7 @@ __global__ __launch_bounds__(1024) void k_scan(QMeta* m0, QMeta* m1)
 }
 
 // Queue 0 of a batch is dense: a single segment that holds every slot.
-__global__ void k_meta_dense(QMeta* m, uint32_t n)
+static __global__ void k_meta_dense(QMeta* m, uint32_t n)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) { m->n = n; m->chunk = n; m->nSeg = 1; m->pad = 0; m->off[0] = 0; m->off[1] = n; }
 }
@@ -364,11 +324,6 @@ FD uint32_t seg_lookup(const uint32_t* sOff, uint32_t nSeg, uint32_t chunk, uint
 // left path is traced, and the right path CONTINUES both random generators where the left path stopped.
 // So the left pass parks the right eye's ray and, when a left path ends, its generator cursors, per sample
 // slot; the right pass starts from those.  g[0] == nullptr: nothing to save (mono, or the right pass).
-struct StereoBuf {
-    double* r[6];      // right-eye ray: origin xyz, direction xyz
-    uint32_t* g[6];    // rnd {j, a, b}, tab {j, a, b} at the end of the left path
-};
-
 FD void path_finish(float* __restrict__ sampleRad, DStats* st, const PathState& s, C3 add, const StereoBuf& SB)
 {
     if (SB.g[0]) {
@@ -386,7 +341,7 @@ FD void path_finish(float* __restrict__ sampleRad, DStats* st, const PathState& 
 // queue is dense (entry = slot); slots of pixels outside the frame (ragged edge buckets) are marked dead.
 #define FRAY_DEAD 0xffffffffu
 template <int ST>
-__global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFrame F, int nItems, int s0, int chunk, PathQueue Q,
+static __global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFrame F, int nItems, int s0, int chunk, PathQueue Q,
                                                  float* __restrict__ sampleRad, const uint32_t* __restrict__ x397, StereoBuf SB, int eye, DStats* st)
 {
     Cnt c = zero_cnt();
@@ -433,7 +388,7 @@ __global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFrame F, 
 }
 
 template <int ST>
-__global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, PathQueue Qin, PathQueue Qout, ShadowQueue SQ, const QMeta* __restrict__ metaIn,
+static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, PathQueue Qin, PathQueue Qout, ShadowQueue SQ, const QMeta* __restrict__ metaIn,
                                                    QMeta* metaOut, QMeta* metaShadow, float* __restrict__ sampleRad, StereoBuf SB, DStats* st)
 {
     __shared__ uint32_t sOff[FRAY_MAXSEG + 1];
@@ -518,7 +473,7 @@ __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, 
 // visible() for every queued next-event segment (main.cpp:64-80, 143-144); the survivor's radiance is
 // added to its sample.  One segment per sample per bounce, so the read-modify-write has no contender.
 template <int ST>
-__global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(DScene S, ShadowQueue SQ, const QMeta* __restrict__ meta,
+static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(DScene S, ShadowQueue SQ, const QMeta* __restrict__ meta,
                                                                         float* __restrict__ sampleRad, DStats* st)
 {
     __shared__ uint32_t sOff[FRAY_MAXSEG + 1];
@@ -543,7 +498,7 @@ __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(DScene S, 
 
 // vfb[y][x] = (sum over samples in order) / spp  (main.cpp:348-360).  `sum` carries the running
 // FP32 sum across batches so the addition order is the reference's.
-__global__ __launch_bounds__(256) void k_pt_resolve(DFrame F, DCamera C, float saturation, int nItems, int s0, int chunk,
+static __global__ __launch_bounds__(256) void k_pt_resolve(DFrame F, DCamera C, float saturation, int nItems, int s0, int chunk,
                                                     const float* __restrict__ sampleRad, const float* __restrict__ sampleRadR,
                                                     float* __restrict__ sum, float* __restrict__ rgb)
 {
@@ -572,20 +527,6 @@ __global__ __launch_bounds__(256) void k_pt_resolve(DFrame F, DCamera C, float s
             rgb[p] = a.r; rgb[p + 1] = a.g; rgb[p + 2] = a.b;
         } else {
             sum[si] = a.r; sum[si + 1] = a.g; sum[si + 2] = a.b;
-        }
-    }
-}
-
-// ---- multi-GPU bucket exchange ----------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack(DFrame F, int nItems, int channels, float* __restrict__ frame, float* __restrict__ packed, int unpack)
-{
-    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < nItems; item += gridDim.x * blockDim.x) {
-        int x, y;
-        bool ok = packed_pixel(F, item, x, y);
-        for (int ch = 0; ch < channels; ch++) {
-            size_t a = ((size_t)y * F.W + x) * channels + ch, b = (size_t)item * channels + ch;
-            if (unpack) { if (ok) frame[a] = packed[b]; }
-            else packed[b] = ok ? frame[a] : 0.0f;
         }
     }
 }

@@ -1,0 +1,250 @@
+// render() of the reference (src/main.cpp:373-405) as kernel launches: frame set-up, the Whitted /
+// primary-ray persistent kernels, the path-tracing batches on several streams, timing and counters.
+// A template over the kernel flag word ST (bit 0: work counters, bit 1: Cube / CSG geometry);
+// render_variant.hip instantiates one ST per translation unit.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+
+#include "render_state.hpp"
+#include "kernels.hpp"
+
+namespace frayhip_detail {
+
+namespace {
+// Carves the SoA path-queue arrays out of the workspace.
+unsigned char* carve_queue(unsigned char* p, size_t n, PathQueue& Q)
+{
+    auto take = [&](size_t bytes) { unsigned char* r = p; p += (bytes + 255) / 256 * 256; return r; };
+    Q.ox = (double*)take(n * 8); Q.oy = (double*)take(n * 8); Q.oz = (double*)take(n * 8);
+    Q.dx = (double*)take(n * 8); Q.dy = (double*)take(n * 8); Q.dz = (double*)take(n * 8);
+    Q.tr = (float*)take(n * 4); Q.tg = (float*)take(n * 4); Q.tb = (float*)take(n * 4);
+    Q.slot = (uint32_t*)take(n * 4); Q.depthFlags = (uint32_t*)take(n * 4);
+    Q.rndJ = (uint32_t*)take(n * 4); Q.rndA = (uint32_t*)take(n * 4); Q.rndB = (uint32_t*)take(n * 4);
+    Q.tabJ = (uint32_t*)take(n * 4); Q.tabA = (uint32_t*)take(n * 4); Q.tabB = (uint32_t*)take(n * 4);
+    return p;
+}
+size_t queue_bytes(size_t n)
+{
+    auto r = [](size_t b) { return (b + 255) / 256 * 256; };
+    return 6 * r(n * 8) + 11 * r(n * 4);
+}
+unsigned char* carve_shadow(unsigned char* p, size_t n, ShadowQueue& Q)
+{
+    auto take = [&](size_t bytes) { unsigned char* r = p; p += (bytes + 255) / 256 * 256; return r; };
+    Q.ax = (double*)take(n * 8); Q.ay = (double*)take(n * 8); Q.az = (double*)take(n * 8);
+    Q.bx = (double*)take(n * 8); Q.by = (double*)take(n * 8); Q.bz = (double*)take(n * 8);
+    Q.cr = (float*)take(n * 4); Q.cg = (float*)take(n * 4); Q.cb = (float*)take(n * 4);
+    Q.slot = (uint32_t*)take(n * 4);
+    return p;
+}
+size_t shadow_bytes(size_t n)
+{
+    auto r = [](size_t b) { return (b + 255) / 256 * 256; };
+    return 6 * r(n * 8) + 4 * r(n * 4);
+}
+}  // namespace
+
+template <int ST>
+int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t* d_id, double* d_dist, hipStream_t stream, frayhip_stats* st)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const frayhip_settings& set = sc->settings;
+    const int W = set.frameWidth, H = set.frameHeight;
+    DFrame F{};
+    F.W = W; F.H = H;
+    F.BW = (W - 1) / 48 + 1; F.BH = (H - 1) / 48 + 1;
+    F.bucketStride = f->bucket_stride > 0 ? f->bucket_stride : 1;
+    F.bucketFirst = f->bucket_first;
+    F.nBuckets = frayhip_bucket_count(W, H, F.bucketFirst, F.bucketStride);
+    if (F.nBuckets < 0) { set_error("frayhip_render: bad bucket_first / bucket_stride"); return FRAYHIP_E_ARG; }
+    if ((long long)F.nBuckets * 2304 > (1ll << 30)) { set_error("frayhip_render: more than 2^30 pixels in one call (shard the frame with bucket_first / bucket_stride)"); return FRAYHIP_E_UNSUPPORTED; }
+    int spp = set.wantAA ? 5 : 1;                                   // main.cpp:395-400
+    if (sc->camera.dof) spp = std::max(spp, sc->camera.numDOFSamples);
+    if (set.gi) spp = std::max(spp, set.numPaths);
+    F.spp = spp;
+    F.seed = f->seed;
+    F.jitter = (sc->camera.dof || set.gi) ? 1 : 0;
+    const int nItems = F.nBuckets * 2304;
+    DScene S = sc->S;
+    S.ambient[0] = set.ambientLight[0]; S.ambient[1] = set.ambientLight[1]; S.ambient[2] = set.ambientLight[2];
+    S.maxTraceDepth = set.maxTraceDepth;
+    S.gi = set.gi;
+    S.saturation = set.saturation;
+    DCamera C = camera_begin_frame(sc->camera, W, H);
+
+    HIP_TRY(hipMemsetAsync(sc->d_stats, 0, kStatsBytes, stream));
+    DCursors* cursors = (DCursors*)((unsigned char*)sc->d_stats + kCursorOffset);
+    HIP_TRY(hipEventRecord(sc->evA, stream));
+    size_t nTraceEvents = 0, nShadowEvents = 0;
+
+    if (f->mode == FRAYHIP_MODE_PRIMARY_ID) {
+        if (nItems > 0) {
+            hipEvent_t a = pool_event(sc->evPool, 0), b = pool_event(sc->evPool, 1);
+            HIP_TRY(hipEventRecord(a, stream));
+            hipLaunchKernelGGL(k_primary<ST>, dim3(persistent_grid(nItems, FRAY_PRIMARY_WAVES)), dim3(256), 0, stream, S, C, F, nItems, d_id, d_dist, sc->d_stats, cursors);
+            HIP_TRY(hipEventRecord(b, stream));
+            nTraceEvents = 2;
+        }
+    } else if (f->mode == FRAYHIP_MODE_RENDER) {
+        if (!d_rgb) { set_error("frayhip_render: MODE_RENDER needs an rgb buffer"); return FRAYHIP_E_ARG; }
+        if (!set.gi) {
+            if (!F.jitter && spp > 5) { set_error("frayhip_render: bad sample count"); return FRAYHIP_E_ARG; }
+            if (nItems > 0) {
+                // workspace: per-thread mt19937 state columns for samples that draw more than 227 words,
+                // then x[397] of every (pixel, sample) seed
+                const int grid = persistent_grid(nItems, FRAY_WHITTED_WAVES);
+                const size_t colBytes = ((size_t)grid * 256 * 624 * sizeof(uint32_t) + 255) / 256 * 256;
+                int rc = ensure_work(sc, colBytes + (size_t)nItems * spp * sizeof(uint32_t));
+                if (rc) return rc;
+                uint32_t* x397 = (uint32_t*)((unsigned char*)sc->d_work + colBytes);
+                hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * spp + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, 0, spp, x397);
+                hipEvent_t a = pool_event(sc->evPool, 0), b = pool_event(sc->evPool, 1);
+                HIP_TRY(hipEventRecord(a, stream));
+                if (sc->whittedNeedsRecursion)
+                    hipLaunchKernelGGL((k_whitted<ST, true>), dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats, cursors);
+                else
+                    hipLaunchKernelGGL((k_whitted<ST, false>), dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats, cursors);
+                HIP_TRY(hipEventRecord(b, stream));
+                nTraceEvents = 2;
+            }
+        } else if (nItems > 0) {
+            if (set.maxTraceDepth > 60) { set_error("frayhip_render: maxTraceDepth above 60 is not supported"); return FRAYHIP_E_UNSUPPORTED; }
+            // Batches of `chunk` samples per pixel; up to FRAY_PT_LANES batches are in flight at once, each on its own
+            // stream with its own queues, so one batch's launch gaps, scans and kernel tails are filled by the others'
+            // blocks.  Only the resolves are ordered (evResolved): the per-pixel sum runs in sample order.
+            const size_t budget = (size_t)1 << FRAY_PT_BUDGET_LOG2;       // paths in flight over all lanes
+            int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / FRAY_PT_LANES / (size_t)nItems);
+            if (chunk > spp) chunk = spp;
+            if (f->spp_chunk <= 0 && spp >= 2 * FRAY_PT_LANES && chunk * FRAY_PT_LANES > spp) chunk = (spp + FRAY_PT_LANES - 1) / FRAY_PT_LANES;   // enough batches to fill the lanes
+            while (chunk > 1 && (size_t)nItems * chunk > ((size_t)1 << 30)) chunk /= 2;   // slots are 32-bit
+            const int nBatches = (spp + chunk - 1) / chunk;
+            const int nLanes = std::min(nBatches, FRAY_PT_LANES);
+            const size_t nPaths = (size_t)nItems * chunk;
+            // per-wave segments round their share up to a multiple of 64: one extra wave-load per wave of the grid
+            const size_t nQueue = nPaths + (size_t)grid_for(nPaths) * 4 * 128;
+            const bool stereo = sc->camera.stereoSeparation > 0;
+            const size_t laneBytes = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + nPaths * 4 + 4096 +
+                                     (stereo ? nPaths * (12 + 6 * 8 + 6 * 4) + 16 * 256 : 0);
+            int rc = ensure_work(sc, (size_t)nLanes * laneBytes + (size_t)nItems * 12 + 4096);
+            if (rc) return rc;
+            struct Lane {
+                hipStream_t stream;
+                PathQueue Q[2];
+                ShadowQueue SQ;
+                float *sampleRad, *sampleRadR;
+                uint32_t* x397;
+                StereoBuf SB;
+                QMeta* meta;
+            } lane[FRAY_PT_LANES];
+            unsigned char* p = (unsigned char*)sc->d_work;
+            float* sum = (float*)p; p += ((size_t)nItems * 12 + 255) / 256 * 256;
+            for (int k = 0; k < nLanes; k++) {
+                Lane& L = lane[k];
+                L.stream = k == 0 ? stream : sc->laneStream[k];
+                L.meta = sc->d_qmeta + 3 * k;
+                p = carve_queue(p, nQueue, L.Q[0]);
+                p = carve_queue(p, nQueue, L.Q[1]);
+                p = carve_shadow(p, nQueue, L.SQ);
+                L.sampleRad = (float*)p; p += (nPaths * 12 + 255) / 256 * 256;
+                L.x397 = (uint32_t*)p; p += (nPaths * 4 + 255) / 256 * 256;
+                L.SB = StereoBuf{};
+                L.sampleRadR = nullptr;
+                if (stereo) {
+                    L.sampleRadR = (float*)p; p += (nPaths * 12 + 255) / 256 * 256;
+                    for (int q = 0; q < 6; q++) { L.SB.r[q] = (double*)p; p += (nPaths * 8 + 255) / 256 * 256; }
+                    for (int q = 0; q < 6; q++) { L.SB.g[q] = (uint32_t*)p; p += (nPaths * 4 + 255) / 256 * 256; }
+                }
+            }
+            const StereoBuf SBnone{};
+            const int nBounce = set.maxTraceDepth + 2;
+            HIP_TRY(hipEventRecord(sc->evLaneStart, stream));               // the side lanes start after whatever precedes this frame on the caller's stream
+            for (int k = 1; k < nLanes; k++) HIP_TRY(hipStreamWaitEvent(sc->laneStream[k], sc->evLaneStart, 0));
+            int batch = 0;
+            for (int s0 = 0; s0 < spp; s0 += chunk, batch++) {
+                const int cn = std::min(chunk, spp - s0);
+                Lane& L = lane[batch % nLanes];
+                hipStream_t ls = L.stream;
+                hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * cn + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, ls, F, nItems, s0, cn, L.x397);
+                for (int eye = 0; eye < (stereo ? 2 : 1); eye++) {
+                    // queue 0 is dense: one segment holding every slot of the batch
+                    hipLaunchKernelGGL(k_meta_dense, dim3(1), dim3(64), 0, ls, L.meta, (uint32_t)((size_t)nItems * cn));
+                    float* rad = eye == 0 ? L.sampleRad : L.sampleRadR;
+                    // left pass of a stereo frame saves generator cursors at path end; mono and the right pass do not
+                    const StereoBuf& save = (stereo && eye == 0) ? L.SB : SBnone;
+                    hipLaunchKernelGGL(k_pt_init<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, ls, S, C, F, nItems, s0, cn, L.Q[0],
+                                       rad, L.x397, L.SB, eye, sc->d_stats);
+                    for (int b = 0; b < nBounce; b++) {
+                        hipEvent_t ea = pool_event(sc->evPool, nTraceEvents), eb = pool_event(sc->evPool, nTraceEvents + 1);
+                        HIP_TRY(hipEventRecord(ea, ls));
+                        hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(bounce_grid((size_t)nItems * cn)), dim3(256), 0, ls, S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ,
+                                           L.meta + (b & 1), L.meta + ((b + 1) & 1), L.meta + 2, rad, save, sc->d_stats);
+                        HIP_TRY(hipEventRecord(eb, ls));
+                        nTraceEvents += 2;
+                        hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, ls, L.meta + ((b + 1) & 1), L.meta + 2);
+                        hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
+                        HIP_TRY(hipEventRecord(ec, ls));
+                        hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, ls, S, L.SQ, L.meta + 2, rad, sc->d_stats + 1);
+                        HIP_TRY(hipEventRecord(ed, ls));
+                        nShadowEvents += 2;
+                    }
+                }
+                // the running per-pixel sum takes the batches in sample order
+                if (batch > 0 && nLanes > 1) HIP_TRY(hipStreamWaitEvent(ls, sc->evResolved[(batch - 1) % nLanes], 0));
+                hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, ls, F, C, set.saturation, nItems, s0, cn, L.sampleRad, L.sampleRadR, sum, d_rgb);
+                HIP_TRY(hipEventRecord(sc->evResolved[batch % nLanes], ls));
+            }
+            // the last resolve follows every earlier one, and each resolve is the last launch of its batch
+            if (nLanes > 1) HIP_TRY(hipStreamWaitEvent(stream, sc->evResolved[(batch - 1) % nLanes], 0));
+        }
+    } else {
+        set_error("frayhip_render: unknown mode");
+        return FRAYHIP_E_ARG;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sc->evB, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    DStats dsv[2];
+    HIP_TRY(hipMemcpy(dsv, sc->d_stats, sizeof dsv, hipMemcpyDeviceToHost));
+    if (dsv[0].rngOverflow || dsv[1].rngOverflow) {
+        set_error("frayhip_render: a camera sample left the supported envelope (path tracing: more than 227 random words per sample; Whitted: shade() nesting deeper than 40; CSG: more than 16 hits on one operand)");
+        return FRAYHIP_E_UNSUPPORTED;
+    }
+    if (st) {
+        // SURVEY 8(d) byte model, evaluated from the counters (zero unless FRAYHIP_FRAME_STATS)
+        auto model = [](const DStats& d) {
+            return 88.0 * (double)d.closest + 73.0 * (double)d.shadow + 168.0 * (double)d.node + 16.0 * (double)d.kdInner + 4.0 * (double)d.leafRefs +
+                   120.0 * (double)d.tri + 32.0 * (double)d.prim + 144.0 * (double)d.smooth + 12.0 * (double)d.tex;
+        };
+        frayhip_stats o{};
+        const DStats &a = dsv[0], &b = dsv[1];
+        o.closest_rays = a.closest + b.closest; o.shadow_rays = a.shadow + b.shadow; o.node_tests = a.node + b.node;
+        o.kd_inner_visits = a.kdInner + b.kdInner; o.leaf_refs = a.leafRefs + b.leafRefs; o.tri_tests = a.tri + b.tri;
+        o.prim_tests = a.prim + b.prim; o.smooth_hits = a.smooth + b.smooth; o.samples = a.samples + b.samples;
+        o.texture_fetches = a.tex + b.tex;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, sc->evA, sc->evB);
+        o.ms_kernels = ms;
+        auto sumEvents = [&](std::vector<hipEvent_t>& pool, size_t n) {
+            double t = 0;
+            for (size_t i = 0; i + 1 < n; i += 2) {
+                float m2 = 0;
+                (void)hipEventElapsedTime(&m2, pool[i], pool[i + 1]);
+                t += m2;
+            }
+            return t;
+        };
+        o.ms_trace = sumEvents(sc->evPool, nTraceEvents);
+        o.trace_launches = nTraceEvents / 2;
+        o.alg_bytes_trace = model(a);
+        o.ms_shadow = sumEvents(sc->evPoolShadow, nShadowEvents);
+        o.shadow_launches = nShadowEvents / 2;
+        o.alg_bytes_shadow = model(b);
+        o.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        *st = o;
+    }
+    return FRAYHIP_OK;
+}
+
+}  // namespace frayhip_detail

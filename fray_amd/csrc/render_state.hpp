@@ -1,0 +1,84 @@
+// Host-side state behind a frayhip_scene handle and the helpers shared by the translation units of
+// the library: capi.hip (scene upload, C entry points) and render_variant.hip (render_impl<ST>, compiled
+// once per kernel flag word so the four variants build in parallel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <string>
+#include <vector>
+
+#include "capi_common.h"
+#include "dev_scene.hpp"
+#include "dev_queues.hpp"
+
+// A failing HIP call: the runtime's own text goes to frayhip_last_error(); the code tells allocation
+// failures (FRAYHIP_E_NOMEM) and a missing device (FRAYHIP_E_NODEVICE) from everything else (FRAYHIP_E_HIP).
+namespace frayhip_detail {
+inline int hip_error_code(hipError_t e)
+{
+    switch (e) {
+        case hipErrorOutOfMemory: return FRAYHIP_E_NOMEM;
+        case hipErrorNoDevice: case hipErrorInvalidDevice: case hipErrorInsufficientDriver: case hipErrorNotInitialized: return FRAYHIP_E_NODEVICE;
+        default: return FRAYHIP_E_HIP;
+    }
+}
+}  // namespace frayhip_detail
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            frayhip_detail::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));         \
+            return frayhip_detail::hip_error_code(e_);                                            \
+        }                                                                                         \
+    } while (0)
+
+#ifndef FRAY_PT_BUDGET_LOG2
+#define FRAY_PT_BUDGET_LOG2 28   // paths in flight over all lanes (240 B each); headline frame: 2^25 138.4, 2^26 135.3, 2^27 135.6, 2^28 133.6 ms
+#endif
+#ifndef FRAY_PT_LANES
+#define FRAY_PT_LANES 4   // headline frame / smallpt 64 spp, ms: 1 lane 150.0 / 136.3, 2 -> 136.9 / 126.5, 3 -> 135.8 / 125.1, 4 -> 135.8 / 123.8, 6 -> 135.2 / 123.9
+#endif
+
+struct frayhip_scene {
+    void* d_arena = nullptr;
+    size_t arena_bytes = 0;
+    DScene S{};
+    frayhip_camera camera{};
+    frayhip_settings settings{};
+    bool whittedNeedsRecursion = false;
+    bool extGeometry = false;         // Cube / CSG nodes present
+    // per-frame workspace, grown on demand and kept between frames
+    void* d_work = nullptr;
+    size_t work_bytes = 0;
+    DStats* d_stats = nullptr;
+    QMeta* d_qmeta = nullptr;         // [3] segment tables: ping-pong path queues + shadow queue
+    hipEvent_t evA = nullptr, evB = nullptr;
+    std::vector<hipEvent_t> evPool, evPoolShadow;
+    // path tracing: batches of a frame run on FRAY_PT_LANES streams at once (lane 0 = the caller's stream)
+    hipStream_t laneStream[FRAY_PT_LANES] = {};
+    hipEvent_t evLaneStart = nullptr, evResolved[FRAY_PT_LANES] = {};
+};
+
+namespace frayhip_detail {
+
+// d_stats: two DStats blocks, then (256-byte aligned) the work cursors; one memset clears all of it per frame
+constexpr size_t kCursorOffset = (2 * sizeof(DStats) + 255) / 256 * 256;
+constexpr size_t kStatsBytes = kCursorOffset + sizeof(DCursors);
+
+DCamera camera_begin_frame(const frayhip_camera& c, int W, int H);
+int persistent_grid(size_t n, int wavesPerSimd);
+int bounce_grid(size_t n);
+int grid_for(size_t n);
+int ensure_work(frayhip_scene* sc, size_t bytes);
+// i-th event of a pool, created on first use; nullptr (and the error text set) when hipEventCreate fails
+hipEvent_t pool_event(std::vector<hipEvent_t>& pool, size_t i);
+
+template <int ST>
+int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t* d_id, double* d_dist, hipStream_t stream, frayhip_stats* st);
+extern template int render_impl<0>(frayhip_scene*, const frayhip_frame*, float*, int32_t*, double*, hipStream_t, frayhip_stats*);
+extern template int render_impl<1>(frayhip_scene*, const frayhip_frame*, float*, int32_t*, double*, hipStream_t, frayhip_stats*);
+extern template int render_impl<2>(frayhip_scene*, const frayhip_frame*, float*, int32_t*, double*, hipStream_t, frayhip_stats*);
+extern template int render_impl<3>(frayhip_scene*, const frayhip_frame*, float*, int32_t*, double*, hipStream_t, frayhip_stats*);
+
+}  // namespace frayhip_detail

@@ -25,9 +25,10 @@ enum {
     FRAYHIP_OK            = 0,
     FRAYHIP_E_ARG         = -1,  /* bad argument (null pointer, bad size, bad mode)          */
     FRAYHIP_E_PARSE       = -2,  /* scene file syntax error / missing file (scene.cpp:544-554) */
-    FRAYHIP_E_NODEVICE    = -3,  /* no HIP device / HIP runtime error                         */
+    FRAYHIP_E_NODEVICE    = -3,  /* no usable HIP device (none present, bad id, no driver)    */
     FRAYHIP_E_UNSUPPORTED = -4,  /* scene uses an element the device path does not implement  */
-    FRAYHIP_E_NOMEM       = -5,
+    FRAYHIP_E_NOMEM       = -5,  /* host or device allocation failed                           */
+    FRAYHIP_E_HIP         = -6,  /* any other HIP runtime failure (launch, copy, event); text in frayhip_last_error() */
 };
 
 /* ---- scene description (flattened `Scene`, scene.h:280-299) ------------------------------ */

@@ -160,6 +160,7 @@ SYMBOLS = {
     "frayhip_scene_create": (C.c_int, [P(SceneDesc), P(VP)]),
     "frayhip_scene_destroy": (None, [VP]),
     "frayhip_scene_set_view": (C.c_int, [VP, P(Camera), P(Settings)]),
+    "frayhip_scene_set_option": (C.c_int, [VP, C.c_char_p, i64]),
     "frayhip_render": (C.c_int, [VP, P(Frame), VP, VP, VP, P(Stats)]),
     "frayhip_render_device": (C.c_int, [VP, P(Frame), VP, VP, VP, VP, P(Stats)]),
     "frayhip_bucket_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

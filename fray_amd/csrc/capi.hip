@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include <functional>
+#include <cstdlib>
 
 
 #include "render_state.hpp"
@@ -525,7 +526,27 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         frayhip_scene_destroy(sc);
         return FRAYHIP_E_NOMEM;
     }
+    // profiling aids: the same knobs as frayhip_scene_set_option, preset from the environment
+    if (const char* e = getenv("FRAYHIP_PT_LANES")) { long v = atol(e); if (v >= 1 && v <= FRAY_PT_LANES) sc->ptLanes = (int)v; }
+    if (const char* e = getenv("FRAYHIP_PT_BUDGET_MIB")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) sc->ptBudgetBytes = (size_t)v << 20; }
     *out = sc;
+    return FRAYHIP_OK;
+}
+
+int frayhip_scene_set_option(frayhip_scene* s, const char* name, int64_t value)
+{
+    if (!s || !name) { set_error("frayhip_scene_set_option: null argument"); return FRAYHIP_E_ARG; }
+    const std::string n(name);
+    if (n == "pt_lanes") {
+        if (value < 1 || value > FRAY_PT_LANES) { set_error("frayhip_scene_set_option: pt_lanes must be 1.." + std::to_string(FRAY_PT_LANES)); return FRAYHIP_E_ARG; }
+        s->ptLanes = (int)value;
+    } else if (n == "pt_budget_mib") {
+        if (value < 1 || value > (1 << 20)) { set_error("frayhip_scene_set_option: pt_budget_mib must be 1..1048576"); return FRAYHIP_E_ARG; }
+        s->ptBudgetBytes = (size_t)value << 20;
+    } else {
+        set_error("frayhip_scene_set_option: unknown option " + n);
+        return FRAYHIP_E_ARG;
+    }
     return FRAYHIP_OK;
 }
 

@@ -8,6 +8,35 @@
 #define FD __device__ __forceinline__
 #include "dev_scene.hpp"
 
+// Diagnostic build only (-DFRAY_STAMPS, never shipped): s_memtime stamps that attribute a wave's cycles to
+// sections of the trace kernels.  STAMP(k) charges the cycles since the wave's previous stamp to section k.  The
+// sums live in LDS (every active lane writes the same value, so any exec mask works) and leave the kernel
+// through DStats.stamp, which nothing else reads.
+#ifdef FRAY_STAMPS
+__shared__ unsigned long long g_stampT0[4];
+__shared__ unsigned long long g_stampAcc[4][16];
+FD void STAMP(int k)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    const int w = threadIdx.x >> 6;
+    g_stampAcc[w][k] += t - g_stampT0[w];
+    g_stampT0[w] = t;
+    __builtin_amdgcn_sched_barrier(0);
+}
+FD void stamp_begin()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    const int w = threadIdx.x >> 6;
+    for (int k = 0; k < 16; k++) g_stampAcc[w][k] = 0;
+    g_stampT0[w] = t;
+}
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 struct V3 { double x, y, z; };
 struct C3 { float r, g, b; };
 

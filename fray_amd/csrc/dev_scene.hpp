@@ -151,6 +151,9 @@ struct DFrame {
 // Device counters mirroring frayhip_stats (only maintained by the *_stats kernel variants).
 struct DStats {
     unsigned long long closest, shadow, node, kdInner, leafRefs, tri, prim, smooth, samples, tex, rngOverflow;   // rngOverflow: any "left the supported envelope" event
+#ifdef FRAY_STAMPS
+    unsigned long long stamp[16];   // diagnostic build: wave cycles per section (dev_math.hpp STAMP)
+#endif
 };
 // Work cursors of the persistent kernels (kernels.hpp claim_items): one per cache line.
 struct DCursors { unsigned int v[8][32]; };

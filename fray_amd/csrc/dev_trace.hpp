@@ -146,7 +146,16 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
     Box6 box;
     box.lox = M.bmin[0]; box.loy = M.bmin[1]; box.loz = M.bmin[2];
     box.hix = M.bmax[0]; box.hiy = M.bmax[1]; box.hiz = M.bmax[2];
-    if (!box_test(box, s, d, rd)) return false;
+    const bool rootHit = box_test(box, s, d, rd);
+    STAMP(2);
+#if defined(FRAY_ABLATE) && FRAY_ABLATE == 1      // timing-only build (wrong pictures): no tree-less triangle loops at all
+    if (!M.hasKd) return false;
+#endif
+#if defined(FRAY_ABLATE) && FRAY_ABLATE == 2      // timing-only build: every lane runs every tree-less triangle loop (no box gating)
+    if (!rootHit && M.hasKd) return false;
+#else
+    if (!rootHit) return false;
+#endif
     gamma = 1e99;
     const int culling = M.culling;
     if (!M.hasKd) {
@@ -154,6 +163,7 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
         const int n = M.nTris;
         for (int i = 0; i < n; i++)
             if (tri_test<ST>(M.tris + i, culling, s, d, gamma, l2, l3, c)) { found = true; tri = i; }
+        STAMP(3);
         return found;
     }
     // ---- stackless KD walk (Mesh::intersectKD, mesh.cpp:357-394) ----
@@ -473,10 +483,14 @@ FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double&
         lr.cls = N.xfClass;
         lr.haveRd = false;
     }
+    STAMP(1);
     V3 ipl;
-    if (!geom_intersect<ST>(S, N, lr, ipl, t, tri, l2, l3, c)) return false;
+    const bool hit = geom_intersect<ST>(S, N, lr, ipl, t, tri, l2, l3, c);
+    STAMP(5);             // whatever geom_intersect did not stamp itself: planes, spheres, the KD walk
+    if (!hit) return false;
     V3 ipw = mulM(ipl, N.T.m) + ld3(N.T.off);
     dist = length(o - ipw);
+    STAMP(6);
     return true;
 }
 
@@ -524,6 +538,7 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitRec& best, Cnt& c)
         const FRAY_RO DNode& W = S.nodes[best.node];
         if (W.geomKind == 3 && S.meshes[W.geomIndex].smooth) c.smooth++;
     }
+    STAMP(6);
     const int nl = S.nLights;
     for (int i = 0; i < nl; i++) {
         double dist;
@@ -532,6 +547,7 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitRec& best, Cnt& c)
             best.dist = dist;
         }
     }
+    STAMP(7);
 }
 
 // visible(a, b), main.cpp:64-80: lights do not occlude; the first node whose (full) intersection

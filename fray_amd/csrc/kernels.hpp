@@ -402,6 +402,9 @@ static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DSc
     const uint32_t begin = w * chunk;
     const uint32_t end = begin + chunk < n ? begin + chunk : n;
     uint32_t produced = 0, producedS = 0;                         // wave-uniform
+#ifdef FRAY_STAMPS
+    stamp_begin();
+#endif
     for (uint32_t base = begin; base < end; base += 64u) {
         const uint32_t di = base + lane;
         bool cont = false, shadow = false;
@@ -416,10 +419,12 @@ static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DSc
         }
         if (live) {
             path_load_ray(Qin, i, ps);
+            STAMP(0);
             // entry test of pathtrace() (main.cpp:173-176) was applied before this path was queued
             HitRec h;
             closest_hit<ST>(S, ps.o, ps.d, h, c);
             path_load_rest(Qin, i, ps);
+            STAMP(8);
             if (h.node <= -2) {                                       // main.cpp:201-208
                 C3 add = (ps.flags & RF_DIFFUSE) ? c3(0, 0, 0) : light_color(S.lights[-2 - h.node]) * ps.pm;
                 path_finish(sampleRad, st, ps, add, SB);
@@ -430,14 +435,17 @@ static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DSc
                 const FRAY_RO DShader& sh = S.shaders[N.shader];
                 HitInfo info;
                 finalize_hit<ST>(S, h, ps.o, ps.d, sh.usesUV || N.bumpTex >= 0, info);
-                            apply_bump<ST>(S, h.node, info, c);
+                apply_bump<ST>(S, h.node, info, c);
+                STAMP(9);
                 mt_skip(ps.tab, spawn_words(sh));                     // the discarded spawnRay (main.cpp:219-224)
                 shadow = nee_prepare(S, ps.d, info, ps.pm, sh, ps.rnd, ps.tab, sa, sb, sc);
+                STAMP(10);
                 PathRay win, wout;
                 win.o = ps.o; win.d = ps.d; win.depth = ps.depth; win.flags = ps.flags;
                 C3 brdf;
                 float pdf;
                 spawn_ray(sh, info, win, ps.tab, wout, brdf, pdf);
+                STAMP(11);
                 if (pdf == -1.0f) {
                     path_finish(sampleRad, st, ps, c3(1, 0, 0), SB);
                 } else if (pdf == 0.0f) {
@@ -451,6 +459,7 @@ static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DSc
                 }
             }
         }
+        STAMP(12);
         const unsigned long long mask = __ballot(cont);
         if (cont) path_store(Qout, begin + produced + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), ps);
         produced += (uint32_t)__popcll(mask);
@@ -463,7 +472,11 @@ static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DSc
             SQ.slot[j] = ps.slot;
         }
         producedS += (uint32_t)__popcll(smask);
+        STAMP(13);
     }
+#ifdef FRAY_STAMPS
+    if (lane < 16) atomicAdd(&st->stamp[lane], g_stampAcc[threadIdx.x >> 6][lane]);
+#endif
     if (lane == 0) { metaOut->cnt[w] = produced; metaShadow->cnt[w] = producedS; }
     if (blockIdx.x == 0 && threadIdx.x == 0) { metaOut->chunk = chunk; metaOut->nSeg = W; metaShadow->chunk = chunk; metaShadow->nSeg = W; }
     if (ST & 1) flush_stats(st, c);
@@ -481,17 +494,27 @@ static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(DSc
     const uint32_t n = meta->n, nSeg = meta->nSeg, chunkIn = meta->chunk;
     for (uint32_t k = threadIdx.x; k <= nSeg; k += blockDim.x) sOff[k] = meta->off[k];
     __syncthreads();
+#ifdef FRAY_STAMPS
+    stamp_begin();
+#endif
     for (uint32_t di = blockIdx.x * blockDim.x + threadIdx.x; di < n; di += gridDim.x * blockDim.x) {
         const uint32_t i = seg_lookup(sOff, nSeg, chunkIn, di);
         V3 a = v3(SQ.ax[i], SQ.ay[i], SQ.az[i]), b = v3(SQ.bx[i], SQ.by[i], SQ.bz[i]);
-        if (visible<ST>(S, a, b, c)) {
+        STAMP(0);
+        const bool vis = visible<ST>(S, a, b, c);
+        STAMP(6);
+        if (vis) {
             C3 add = c3(SQ.cr[i], SQ.cg[i], SQ.cb[i]);
             if (add.r != 0 || add.g != 0 || add.b != 0) {
                 size_t q = (size_t)SQ.slot[i] * 3;
                 sampleRad[q] += add.r; sampleRad[q + 1] += add.g; sampleRad[q + 2] += add.b;
             }
         }
+        STAMP(13);
     }
+#ifdef FRAY_STAMPS
+    if ((threadIdx.x & 63) < 16) atomicAdd(&st->stamp[threadIdx.x & 63], g_stampAcc[threadIdx.x >> 6][threadIdx.x & 63]);
+#endif
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <cstdio>
 
 #include "render_state.hpp"
 #include "kernels.hpp"
@@ -114,13 +115,14 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             // Batches of `chunk` samples per pixel; up to FRAY_PT_LANES batches are in flight at once, each on its own
             // stream with its own queues, so one batch's launch gaps, scans and kernel tails are filled by the others'
             // blocks.  Only the resolves are ordered (evResolved): the per-pixel sum runs in sample order.
-            const size_t budget = (size_t)1 << FRAY_PT_BUDGET_LOG2;       // paths in flight over all lanes
-            int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / FRAY_PT_LANES / (size_t)nItems);
+            const int maxLanes = std::max(1, std::min(sc->ptLanes, FRAY_PT_LANES));
+            const size_t budget = std::max<size_t>(sc->ptBudgetBytes / 240, 1);       // paths in flight over all lanes (240 B each)
+            int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / maxLanes / (size_t)nItems);
             if (chunk > spp) chunk = spp;
-            if (f->spp_chunk <= 0 && spp >= 2 * FRAY_PT_LANES && chunk * FRAY_PT_LANES > spp) chunk = (spp + FRAY_PT_LANES - 1) / FRAY_PT_LANES;   // enough batches to fill the lanes
+            if (f->spp_chunk <= 0 && spp >= 2 * maxLanes && chunk * maxLanes > spp) chunk = (spp + maxLanes - 1) / maxLanes;   // enough batches to fill the lanes
             while (chunk > 1 && (size_t)nItems * chunk > ((size_t)1 << 30)) chunk /= 2;   // slots are 32-bit
             const int nBatches = (spp + chunk - 1) / chunk;
-            const int nLanes = std::min(nBatches, FRAY_PT_LANES);
+            const int nLanes = std::min(nBatches, maxLanes);
             const size_t nPaths = (size_t)nItems * chunk;
             // per-wave segments round their share up to a multiple of 64: one extra wave-load per wave of the grid
             const size_t nQueue = nPaths + (size_t)grid_for(nPaths) * 4 * 128;
@@ -207,6 +209,19 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     HIP_TRY(hipStreamSynchronize(stream));
     DStats dsv[2];
     HIP_TRY(hipMemcpy(dsv, sc->d_stats, sizeof dsv, hipMemcpyDeviceToHost));
+#ifdef FRAY_STAMPS
+    {
+        static const char* names[16] = {"queue lookup + ray load", "local ray (transform)", "root box test", "tree-less triangle loop", "-", "other geometry (plane/sphere/KD)",
+                                        "node finish + compare", "lights", "load rest of path", "finalize hit + bump", "discarded spawn + NEE prepare", "spawn ray",
+                                        "throughput + finish", "queue stores", "-", "-"};
+        for (int q = 0; q < 2; q++) {
+            double tot = 0;
+            for (int k = 0; k < 16; k++) tot += (double)dsv[q].stamp[k];
+            fprintf(stderr, "[stamps] %s: total %.4g wave-cycles\n", q == 0 ? "k_pt_bounce (+ other kernels on this DStats)" : "k_pt_shadow", tot);
+            for (int k = 0; k < 16; k++) if (dsv[q].stamp[k]) fprintf(stderr, "[stamps]   %-36s %6.2f %%\n", names[k], 100.0 * (double)dsv[q].stamp[k] / tot);
+        }
+    }
+#endif
     if (dsv[0].rngOverflow || dsv[1].rngOverflow) {
         set_error("frayhip_render: a camera sample left the supported envelope (path tracing: more than 227 random words per sample; Whitted: shade() nesting deeper than 40; CSG: more than 16 hits on one operand)");
         return FRAYHIP_E_UNSUPPORTED;

@@ -33,8 +33,8 @@ inline int hip_error_code(hipError_t e)
         }                                                                                         \
     } while (0)
 
-#ifndef FRAY_PT_BUDGET_LOG2
-#define FRAY_PT_BUDGET_LOG2 28   // paths in flight over all lanes (240 B each); headline frame: 2^25 138.4, 2^26 135.3, 2^27 135.6, 2^28 133.6 ms
+#ifndef FRAY_PT_BUDGET_MIB
+#define FRAY_PT_BUDGET_MIB 65536   // default workspace budget of a path-traced frame (frayhip_scene_set_option "pt_budget_mib"); 240 B per path in flight
 #endif
 #ifndef FRAY_PT_LANES
 #define FRAY_PT_LANES 4   // headline frame / smallpt 64 spp, ms: 1 lane 150.0 / 136.3, 2 -> 136.9 / 126.5, 3 -> 135.8 / 125.1, 4 -> 135.8 / 123.8, 6 -> 135.2 / 123.9
@@ -58,6 +58,9 @@ struct frayhip_scene {
     // path tracing: batches of a frame run on FRAY_PT_LANES streams at once (lane 0 = the caller's stream)
     hipStream_t laneStream[FRAY_PT_LANES] = {};
     hipEvent_t evLaneStart = nullptr, evResolved[FRAY_PT_LANES] = {};
+    // tunables (frayhip_scene_set_option; defaults from FRAYHIP_PT_LANES / FRAYHIP_PT_BUDGET_MIB in the environment)
+    int ptLanes = FRAY_PT_LANES;
+    size_t ptBudgetBytes = (size_t)FRAY_PT_BUDGET_MIB << 20;
 };
 
 namespace frayhip_detail {

@@ -110,6 +110,12 @@ class Scene:
             lib.frayhip_scene_destroy(self._dev)
             self._dev = C.c_void_p()
 
+    def set_option(self, name, value):
+        """frayhip_scene_set_option: "pt_lanes" (1..4 batches in flight), "pt_budget_mib" (queue memory)."""
+        self._need_dev()
+        _check(lib.frayhip_scene_set_option(self._dev, name.encode(), int(value)))
+        return self
+
     def _frame(self, mode, seed, bucket_first, bucket_stride, spp_chunk, stats):
         return abi.Frame(mode=mode, seed=seed, bucket_first=bucket_first, bucket_stride=bucket_stride,
                          spp_chunk=spp_chunk, flags=abi.FRAME_STATS if stats else 0)

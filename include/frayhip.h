@@ -263,6 +263,14 @@ void frayhip_scene_destroy(frayhip_scene* s);
  * Camera::beginFrame re-derives everything per frame anyway).  Either pointer may be NULL. */
 int  frayhip_scene_set_view(frayhip_scene* s, const frayhip_camera* camera, const frayhip_settings* settings);
 
+/* Tunables of an uploaded scene (value ranges checked, FRAYHIP_E_ARG otherwise):
+ *   "pt_lanes"      1..4   path-tracing batches in flight at once, each on its own HIP stream (default 4;
+ *                          1 serialises every launch, which is what a per-kernel profile wants)
+ *   "pt_budget_mib" MiB of device memory a path-traced frame may use for its queues (240 B per path in
+ *                          flight; default 65536): a frame is cut into batches of samples that fit
+ * The environment variables FRAYHIP_PT_LANES / FRAYHIP_PT_BUDGET_MIB preset them at frayhip_scene_create. */
+int  frayhip_scene_set_option(frayhip_scene* s, const char* name, int64_t value);
+
 /* Threads: a frayhip_scene renders one frame at a time (it owns one workspace and one set of
  * counters), as the reference calls render() from one thread at a time (main.cpp:407-412,448);
  * different scenes may be driven from different threads.  frayhip_last_error() is per thread. */

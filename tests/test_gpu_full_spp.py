@@ -1,0 +1,46 @@
+"""BASELINE.json configs[2], [3] and [4] at their FULL sample counts on one MI355X (the 8-GPU configs shard the
+same frame by buckets, so one GPU rendering every bucket computes exactly the pixels eight would).
+
+The whole frame is rendered by the HIP path -- all batches, all four batch lanes, the ordered per-pixel
+resolves (src/main.cpp:348-360, 395-400) -- and a strided set of the reference's 48x48 buckets of that very
+frame is compared with the oracle's render of those buckets: per-channel RMS <= 1e-4 (north_star), and the
+camera-sample counters must be exact on both sides."""
+import numpy as np
+import pytest
+
+from conftest import open_scene
+
+pytestmark = pytest.mark.gpu
+RMS_TOL = 1e-4          # per channel, north_star
+
+CASES = [
+    # scene, W, H, overrides, (first, stride) of the oracle's buckets, id
+    ("cornell_box.fray", 1920, 1080, dict(gi=1, numPaths=64), (17, 40), "configs2-cornell-1080p-pt64"),
+    ("forest.fray", 1920, 1080, dict(wantAA=0, dof=1, numDOFSamples=256, interactive=0), (7, 40), "configs3-forest-1080p-dof256"),
+    ("smallpt.fray", 4096, 4096, dict(gi=1, numPaths=1024), (1111, 1800), "configs4-smallpt-4096-pt1024"),
+]
+
+
+@pytest.mark.parametrize("scene,W,H,over,strip,name", CASES, ids=[c[5] for c in CASES])
+def test_full_spp_frame_vs_oracle_buckets(fray, abi, oracle, gpu, scene, W, H, over, strip, name):
+    s = open_scene(fray, scene, W, H, **over)
+    s.beginRender()
+    spp = s.samples_per_pixel()
+    assert spp == max(over.get("numPaths", 0), over.get("numDOFSamples", 0))
+    img, st = s.render(seed=42, stats=True)            # instrumented kernel variants: same picture, plus counters
+    assert np.all(np.isfinite(img))
+    assert st["samples"] == W * H * spp                 # every camera sample of the frame was traced, once
+    first, stride = strip
+    ref, ost = oracle.render(s.desc, abi.MODE_RENDER, seed=42, bucket_first=first, bucket_stride=stride, threads=16)
+    BW, BH = (W - 1) // 48 + 1, (H - 1) // 48 + 1
+    mask = np.zeros((H, W), bool)
+    for b in range(first, BW * BH, stride):
+        by, bx = divmod(b, BW)
+        mask[by * 48:by * 48 + 48, bx * 48:bx * 48 + 48] = True
+    assert mask.sum() >= 3 * 2304 - 48 * 48             # at least three buckets (a ragged edge bucket may be smaller)
+    assert ost["samples"] == int(mask.sum()) * spp
+    assert not ref[~mask].any() and ref[mask].mean() > 1e-3
+    d = (img[mask].astype(np.float64) - ref[mask]) ** 2
+    rms = np.sqrt(d.mean(axis=0))
+    assert np.all(rms <= RMS_TOL), rms
+    s.close()

@@ -310,6 +310,8 @@ def main():
                          "launches_per_step": trace_launches / args.steps,
                          "note": "algorithmic bytes per SURVEY 8(d); scene tables are L2/LDS resident, so this is not HBM traffic"},
             "kernel_ms_per_step": kernels_ms / args.steps,
+            "launch_ms_sums_per_step": {"trace": trace_ms / args.steps, "shadow": shadow_ms / args.steps,
+                                        "launches": [trace_launches / args.steps, shadow_launches / args.steps]},
         }
         if shadow_launches and kernels_ms > 0:
             # Path-tracing batches run on several streams at once, so the launches of different batches overlap and a

@@ -336,7 +336,8 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         int sk = d.shaders[n.shader].kind;
         if (sk == FRAYHIP_SHADER_REFL || sk == FRAYHIP_SHADER_REFR || sk == FRAYHIP_SHADER_LAYERED) sc->whittedNeedsRecursion = true;
     }
-    size_t oNodes = A.add(nodes.data(), nodes.size() * sizeof(DNode));
+    size_t oNodes = A.add(nullptr, 0);                  // filled after the meshes: tree-less nodes hold a device pointer
+    A.host.resize(oNodes + nodes.size() * sizeof(DNode));
     std::vector<DPlane> planes(d.n_planes);
     for (int i = 0; i < d.n_planes; i++) { planes[i].limit = d.planes[i].limit; planes[i].height = d.planes[i].height; }
     size_t oPlanes = A.add(planes.data(), planes.size() * sizeof(DPlane));
@@ -490,6 +491,17 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         meshes[mi].refs = (const FRAY_RO int32_t*)(base + moff[mi].refs);
     }
     if (!meshes.empty()) memcpy(A.host.data() + oMeshes, meshes.data(), meshes.size() * sizeof(DMesh));
+    for (int i = 0; i < d.n_nodes; i++) {
+        DNode& N = nodes[i];
+        N.tlTris = 0; N.tlCulling = 0; N.pad = 0; N.tlPtr = nullptr;
+        for (int k = 0; k < 3; k++) N.bmin[k] = N.bmax[k] = 0;
+        if (N.geomKind == FRAYHIP_GEOM_MESH && !meshes[N.geomIndex].hasKd) {
+            const DMesh& M = meshes[N.geomIndex];
+            N.tlTris = M.nTris; N.tlCulling = M.culling; N.tlPtr = M.tris;
+            put3(N.bmin, M.bmin); put3(N.bmax, M.bmax);
+        }
+    }
+    if (!nodes.empty()) memcpy(A.host.data() + oNodes, nodes.data(), nodes.size() * sizeof(DNode));
     for (int i = 0; i < d.n_textures; i++) tex[i].texels = (const FRAY_RO float*)(base + oTexels) + d.textures[i].texel_offset;
     if (!tex.empty()) memcpy(A.host.data() + oTex, tex.data(), tex.size() * sizeof(DTexture));
     hipError_t e = hipMemcpy(sc->d_arena, A.host.data(), A.host.size(), hipMemcpyHostToDevice);

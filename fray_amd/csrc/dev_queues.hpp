@@ -2,6 +2,7 @@
 // (kernels.hpp) and by the host code that carves them out of the workspace (render_impl.hpp).
 #pragma once
 #include <stdint.h>
+#include "dev_scene.hpp"   // FRAY_RO
 
 struct PathQueue {
     double* ox; double* oy; double* oz;
@@ -32,6 +33,10 @@ struct QMeta {
     uint32_t cnt[FRAY_MAXSEG];
     uint32_t off[FRAY_MAXSEG + 1];
 };
+
+// The same table as a kernel argument that is only read: typed into the constant address space on the device, so
+// the offsets come through the scalar cache (as the scene tables do, dev_scene.hpp).
+struct QMetaRO { const FRAY_RO QMeta* p; };
 
 // Right-eye state parked by the left pass of a stereo path-traced frame (kernels.hpp, k_pt_init).
 struct StereoBuf {

@@ -33,12 +33,20 @@
 
 struct DXform { double off[3]; double m[9]; double inv[9]; };
 
+struct DTri;
 struct DNode {
     DXform T;
     int32_t geomKind, geomIndex, shader, bumpTex;
-    int32_t xfClass;      // index of the first node whose {offset, invM} is bitwise equal: nodes of one
-    int32_t pad;          // class see the same local ray, so it is computed once per ray (e.g. the 7
-};                        // untransformed Cornell-box meshes)
+    int32_t xfClass;      // index of the first node whose {offset, invM} is bitwise equal: nodes of one class see the
+                          // same local ray, so it is computed once per ray (e.g. the 7 untransformed Cornell-box meshes)
+    // A mesh WITHOUT a KD-tree (Mesh::intersect's brute-force loop, mesh.cpp:157-161: at most 20 triangles) carries a
+    // copy of what its root box test and triangle loop read, so neither needs a second dependent load through DMesh:
+    int32_t tlTris;       // number of triangles; 0 for every other geometry
+    int32_t tlCulling;
+    int32_t pad;
+    double bmin[3], bmax[3];
+    const FRAY_RO DTri* tlPtr;
+};                        // 256 B
 
 struct DPlane { double limit, height; };
 struct DSphere { double O[3]; double R; };

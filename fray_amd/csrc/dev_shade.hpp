@@ -19,7 +19,7 @@ struct HitInfo {           // IntersectionInfo, geometry.h:33-39 (after Node::in
 // (geometry.cpp:30-83, 196-208; mesh.cpp:112-137).  needUV gates the sphere's atan2/asin, whose
 // result only textures and bump maps read.
 // Local normal / uv of a non-CSG geometry at local point ipl (what its intersect() writes).
-FD void prim_attributes(const DScene& S, int kind, int index, V3 ipl, int code, double l2, double l3, bool needUV, V3& nl, HitInfo& info)
+FD void prim_attributes(const DScene& S, int kind, int index, V3 ipl, int code, double l2, double l3, bool needUV, bool needBump, V3& nl, HitInfo& info)
 {
     if (kind == 0) {
         nl = v3(0, 1, 0);
@@ -52,15 +52,19 @@ FD void prim_attributes(const DScene& S, int kind, int index, V3 ipl, int code, 
             info.u = A->tA[0] + (A->tB[0] - A->tA[0]) * l2 + (A->tC[0] - A->tA[0]) * l3;
             info.v = A->tA[1] + (A->tB[1] - A->tA[1]) * l2 + (A->tC[1] - A->tA[1]) * l3;
         }
-        info.dNdx = ld3(A->dNdx);
-        info.dNdy = ld3(A->dNdy);
+        if (needBump) {                       // only BumpTexture::modifyNormal reads them (shading.cpp:397-418)
+            info.dNdx = ld3(A->dNdx);
+            info.dNdy = ld3(A->dNdy);
+        }
     }
 }
 
-template <int ST>
+// BARY: the hit record carries no barycentrics (the path tracer's hit queue): they are re-derived for meshes that read them.
+template <int ST, bool BARY = false>
 FD void finalize_hit(const DScene& S, const HitRec& h, V3 o, V3 d, bool needUV, HitInfo& info)
 {
     const FRAY_RO DNode& N = S.nodes[h.node];
+    const bool needBump = N.bumpTex >= 0;
     V3 ls = mulM(o - ld3(N.T.off), N.T.inv);
     V3 ldir = normalized(mulM(d, N.T.inv));
     V3 ipl = ls + ldir * h.t;
@@ -72,7 +76,7 @@ FD void finalize_hit(const DScene& S, const HitRec& h, V3 o, V3 d, bool needUV, 
         GHit g;
         cube_intersect(S.cubes[N.geomIndex], ls, ldir, g);       // same arithmetic as during the search
         ipl = g.ip;
-        prim_attributes(S, 2, N.geomIndex, ipl, g.code, 0, 0, needUV, nl, info);
+        prim_attributes(S, 2, N.geomIndex, ipl, g.code, 0, 0, needUV, needBump, nl, info);
     } else if ((ST & 2) && N.geomKind == 4) {
         const FRAY_RO DCsg& G = S.csgs[N.geomIndex];
         GHit g;
@@ -81,9 +85,14 @@ FD void finalize_hit(const DScene& S, const HitRec& h, V3 o, V3 d, bool needUV, 
         dummy.envelope = 0;
         csg_intersect<(ST & 2), FRAY_CSG_DEPTH - 1>(S, G, ls, ldir, ray_rdir(ldir), g, env, dummy);
         ipl = g.ip;
-        prim_attributes(S, g.leafKind, g.leafIndex, ipl, g.code, g.l2, g.l3, needUV, nl, info);
+        prim_attributes(S, g.leafKind, g.leafIndex, ipl, g.code, g.l2, g.l3, needUV, needBump, nl, info);
     } else {
-        prim_attributes(S, N.geomKind, N.geomIndex, ipl, h.tri, h.l2, h.l3, needUV, nl, info);
+        double l2 = h.l2, l3 = h.l3;
+        if (BARY && N.geomKind == 3) {
+            const FRAY_RO DMesh& M = S.meshes[N.geomIndex];
+            if (M.smooth || M.hasUV) tri_bary(M.tris + h.tri, ls, ldir, l2, l3);
+        }
+        prim_attributes(S, N.geomKind, N.geomIndex, ipl, h.tri, l2, l3, needUV, needBump, nl, info);
     }
     info.ip = mulM(ipl, N.T.m) + ld3(N.T.off);
     info.norm = normalized(mulM(nl, N.T.m));

@@ -131,6 +131,18 @@ FD bool tri_test(const FRAY_RO DTri* T, int culling, V3 s, V3 d, double& best, d
     return ok;
 }
 
+// Mesh::intersectTriangle's barycentrics for a triangle already known to be the winner (the hit queue carries
+// {node, triangle, gamma}; l2 / l3 are only read by smooth or textured meshes): tri_test's expressions again.
+FD void tri_bary(const FRAY_RO DTri* T, V3 s, V3 d, double& l2, double& l3)
+{
+    const V3 N = ld3(T->N), A = ld3(T->A), AC = ld3(T->AC), AB = ld3(T->AB);
+    const V3 D = -d;
+    const double rDcr = 1 / dot(N, D);
+    const V3 H = s - A;
+    l2 = dot(cross(H, AC), D) * rDcr;
+    l3 = dot(cross(AB, H), D) * rDcr;
+}
+
 // Mesh::intersect (mesh.cpp:144-165).  On true: gamma / tri / l2 / l3 describe info.
 template <int ST>
 FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int& tri, double& l2, double& l3, Cnt& c)
@@ -148,14 +160,7 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
     box.hix = M.bmax[0]; box.hiy = M.bmax[1]; box.hiz = M.bmax[2];
     const bool rootHit = box_test(box, s, d, rd);
     STAMP(2);
-#if defined(FRAY_ABLATE) && FRAY_ABLATE == 1      // timing-only build (wrong pictures): no tree-less triangle loops at all
-    if (!M.hasKd) return false;
-#endif
-#if defined(FRAY_ABLATE) && FRAY_ABLATE == 2      // timing-only build: every lane runs every tree-less triangle loop (no box gating)
-    if (!rootHit && M.hasKd) return false;
-#else
     if (!rootHit) return false;
-#endif
     gamma = 1e99;
     const int culling = M.culling;
     if (!M.hasKd) {
@@ -463,9 +468,24 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, LocalRay& lr, V3
         return true;
     }
     // mesh
-    const FRAY_RO DMesh& M = S.meshes[N.geomIndex];
     double gamma;
-    if (!mesh_intersect<ST>(M, lr, gamma, tri, l2, l3, c)) return false;
+    if (N.tlTris > 0) {      // no KD-tree: Mesh::intersect's brute-force loop (mesh.cpp:146-161) on the node's own copy of the mesh header
+        if (!lr.haveRd) { lr.rd = ray_rdir(ld); lr.haveRd = true; }
+        Box6 box;
+        box.lox = N.bmin[0]; box.loy = N.bmin[1]; box.loz = N.bmin[2];
+        box.hix = N.bmax[0]; box.hiy = N.bmax[1]; box.hiz = N.bmax[2];
+        const bool rootHit = box_test(box, ls, ld, lr.rd);
+        STAMP(2);
+        if (!rootHit) return false;
+        gamma = 1e99;
+        bool found = false;
+        const int n = N.tlTris, culling = N.tlCulling;
+        const FRAY_RO DTri* tris = N.tlPtr;
+        for (int i = 0; i < n; i++)
+            if (tri_test<ST>(tris + i, culling, ls, ld, gamma, l2, l3, c)) { found = true; tri = i; }
+        STAMP(3);
+        if (!found) return false;
+    } else if (!mesh_intersect<ST>(S.meshes[N.geomIndex], lr, gamma, tri, l2, l3, c)) return false;
     ipl = ls + ld * gamma;
     t = gamma;
     return true;

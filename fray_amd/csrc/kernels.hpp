@@ -27,7 +27,7 @@
 #define FRAY_SHADOW_WAVES 4
 #endif
 #ifndef FRAY_BOUNCE_WAVES
-#define FRAY_BOUNCE_WAVES 3   // waves per SIMD the bounce kernel is register-allocated for (measured: 2 -> 215 ms, 3 -> 183 ms, 4 -> 183 ms)
+#define FRAY_BOUNCE_WAVES 3   // waves per SIMD the bounce kernel is register-allocated for
 #endif
 
 // ---- work item -> pixel ------------------------------------------------------------------------
@@ -278,8 +278,8 @@ FD void path_load_rest(const PathQueue& Q, uint32_t i, PathState& s)
 // producing kernel owns a contiguous range of input paths and writes its survivors, ranked by a
 // ballot prefix count, into its own contiguous segment of the output queue (capacity = its input
 // share, so it cannot overflow); it publishes one count.  A one-block scan turns the counts into
-// offsets, and a consumer lane maps its dense index to (segment, position) by a 13-step binary
-// search over the offsets held in LDS.
+// offsets; a consuming wave owns a contiguous range of dense indices and follows the segments that hold them
+// with a cursor (seg_map below).
 static __global__ __launch_bounds__(1024) void k_scan(QMeta* m0, QMeta* m1)
 {
     QMeta* m = blockIdx.x == 0 ? m0 : m1;
@@ -309,15 +309,31 @@ static __global__ void k_meta_dense(QMeta* m, uint32_t n)
     if (blockIdx.x == 0 && threadIdx.x == 0) { m->n = n; m->chunk = n; m->nSeg = 1; m->pad = 0; m->off[0] = 0; m->off[1] = n; }
 }
 
-// Dense index -> storage index of a segmented queue (sOff = offsets in LDS).
-FD uint32_t seg_lookup(const uint32_t* sOff, uint32_t nSeg, uint32_t chunk, uint32_t i)
+// Dense index -> storage index of a segmented queue without a table in LDS: a wave walks a contiguous range of
+// dense indices, so the segment that holds them only ever moves forward.  `seg` is the wave's cursor (uniform);
+// the offsets are read on the scalar path.  seg_map returns the storage index of dense entry `di` of the 64-entry
+// batch that starts at `base` (garbage for lanes that are not `live`).
+FD uint32_t seg_first(const FRAY_RO uint32_t* off, uint32_t nSeg, uint32_t begin)
 {
-    uint32_t lo = 0, hi = nSeg;
+    uint32_t lo = 0, hi = nSeg;       // largest s with off[s] <= begin
     while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (sOff[mid] <= i) lo = mid; else hi = mid;
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= begin) lo = mid; else hi = mid;
     }
-    return lo * chunk + (i - sOff[lo]);
+    return lo;
+}
+FD uint32_t seg_map(const FRAY_RO uint32_t* off, uint32_t nSeg, uint32_t chunk, uint32_t base, uint32_t di, bool live, uint32_t& seg)
+{
+    while (seg + 1 < nSeg && off[seg + 1] <= base) seg++;
+    uint32_t i = 0, s = seg, lo = off[s];
+    for (;;) {                        // the segments that overlap this batch: one, now and then two
+        const uint32_t hi = off[s + 1];
+        if (live && di >= lo && di < hi) i = s * chunk + (di - lo);
+        if (hi >= base + 64u || s + 1 >= nSeg) break;
+        s++;
+        lo = hi;
+    }
+    return i;
 }
 
 // Stereo path tracing (raytraceSinglePixel, main.cpp:306-317): both eye rays are generated first, the
@@ -387,36 +403,108 @@ static __global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFr
     if (ST & 1) flush_stats(st, c);
 }
 
-template <int ST>
-static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, PathQueue Qin, PathQueue Qout, ShadowQueue SQ, const QMeta* __restrict__ metaIn,
-                                                   QMeta* metaOut, QMeta* metaShadow, float* __restrict__ sampleRad, StereoBuf SB, DStats* st)
+// ---- one bounce = trace, shade, shadow -------------------------------------------------------------------
+// Every wave of these three kernels owns the same contiguous range of the input queue's dense indices (its
+// share = the segment capacity of what it writes), and walks it in order.
+struct WaveShare { uint32_t begin, end, chunk, w, W; };
+FD WaveShare wave_share(uint32_t n)
 {
-    __shared__ uint32_t sOff[FRAY_MAXSEG + 1];
-    Cnt c = zero_cnt();
-    const uint32_t n = metaIn->n, nSegIn = metaIn->nSeg, chunkIn = metaIn->chunk;
-    for (uint32_t k = threadIdx.x; k <= nSegIn; k += blockDim.x) sOff[k] = metaIn->off[k];
-    __syncthreads();
-    const uint32_t W = gridDim.x * (blockDim.x >> 6), w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    WaveShare r;
+    r.W = gridDim.x * (blockDim.x >> 6);
+    r.w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    r.chunk = (((n + r.W - 1u) / r.W) + 63u) & ~63u;
+    r.begin = r.w * r.chunk;
+    r.end = r.begin + r.chunk < n ? r.begin + r.chunk : n;
+    if (r.begin > n) r.begin = r.end = n;
+    return r;
+}
+
+// What pathtrace() does with a path once its closest hit is known (main.cpp:201-242): light / environment hits end
+// it; otherwise bump, the discarded spawnRay, the next-event sample (everything but its visibility query -> `shadow`
+// segment sa -> sb carrying sc), the real spawnRay, the throughput update and the entry test of the next iteration
+// (`cont`: ps is the path to continue).
+template <int ST, bool BARY>
+FD void path_shade(const DScene& S, PathState& ps, const HitRec& h, float* __restrict__ sampleRad, DStats* st, const StereoBuf& SB, bool& cont, bool& shadow,
+                   V3& sa, V3& sb, C3& sc, Cnt& c)
+{
+    if (h.node <= -2) {                                       // main.cpp:201-208
+        C3 add = (ps.flags & RF_DIFFUSE) ? c3(0, 0, 0) : light_color(S.lights[-2 - h.node]) * ps.pm;
+        path_finish(sampleRad, st, ps, add, SB);
+    } else if (h.node < 0) {                                  // main.cpp:210-215
+        path_finish(sampleRad, st, ps, environment<ST>(S, ps.d, c) * ps.pm, SB);
+    } else {
+        const FRAY_RO DNode& N = S.nodes[h.node];
+        const FRAY_RO DShader& sh = S.shaders[N.shader];
+        HitInfo info;
+        finalize_hit<ST, BARY>(S, h, ps.o, ps.d, sh.usesUV || N.bumpTex >= 0, info);
+        apply_bump<ST>(S, h.node, info, c);
+        mt_skip(ps.tab, spawn_words(sh));                     // the discarded spawnRay (main.cpp:219-224)
+        shadow = nee_prepare(S, ps.d, info, ps.pm, sh, ps.rnd, ps.tab, sa, sb, sc);
+        PathRay win, wout;
+        win.o = ps.o; win.d = ps.d; win.depth = ps.depth; win.flags = ps.flags;
+        C3 brdf;
+        float pdf;
+        spawn_ray(sh, info, win, ps.tab, wout, brdf, pdf);
+        if (pdf == -1.0f) {
+            path_finish(sampleRad, st, ps, c3(1, 0, 0), SB);
+        } else if (pdf == 0.0f) {
+            path_finish(sampleRad, st, ps, c3(0, 0, 0), SB);
+        } else {
+            ps.pm = ps.pm * brdf / pdf;
+            ps.o = wout.o; ps.d = wout.d; ps.depth = wout.depth; ps.flags = wout.flags;
+            // entry test of the next pathtrace() call (main.cpp:173-176)
+            if (ps.depth > S.maxTraceDepth || intensity(ps.pm) < 0.01) path_finish(sampleRad, st, ps, c3(0, 0, 0), SB);
+            else cont = true;
+        }
+    }
+}
+
+// Survivors and next-event segments of one batch of 64 paths go to the wave's own segments of the output queues
+// (ballot rank, no global counter).
+FD void bounce_emit(const PathQueue& Qout, const ShadowQueue& SQ, uint32_t segBegin, uint32_t& produced, uint32_t& producedS, bool cont, bool shadow,
+                    const PathState& ps, V3 sa, V3 sb, C3 sc)
+{
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t chunk = (((n + W - 1u) / W) + 63u) & ~63u;    // this launch's per-wave share = output segment size
-    const uint32_t begin = w * chunk;
-    const uint32_t end = begin + chunk < n ? begin + chunk : n;
+    const unsigned long long mask = __ballot(cont);
+    if (cont) path_store(Qout, segBegin + produced + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), ps);
+    produced += (uint32_t)__popcll(mask);
+    const unsigned long long smask = __ballot(shadow);
+    if (shadow) {
+        const uint32_t j = segBegin + producedS + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull));
+        SQ.ax[j] = sa.x; SQ.ay[j] = sa.y; SQ.az[j] = sa.z;
+        SQ.bx[j] = sb.x; SQ.by[j] = sb.y; SQ.bz[j] = sb.z;
+        SQ.cr[j] = sc.r; SQ.cg[j] = sc.g; SQ.cb[j] = sc.b;
+        SQ.slot[j] = ps.slot;
+    }
+    producedS += (uint32_t)__popcll(smask);
+}
+
+// **Dominant kernel**: one pathtrace() iteration (main.cpp:171-244) for every live path of the queue: closest hit,
+// then path_shade.  Every wave owns a contiguous share of the queue's dense indices and writes its survivors and
+// next-event segments into its own segments of the output queues.
+template <int ST>
+static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, PathQueue Qin, PathQueue Qout, ShadowQueue SQ, QMetaRO metaIn,
+                                                                          QMeta* metaOut, QMeta* metaShadow, float* __restrict__ sampleRad, StereoBuf SB, DStats* st)
+{
+    Cnt c = zero_cnt();
+    const FRAY_RO uint32_t* off = metaIn.p->off;
+    const uint32_t nSeg = metaIn.p->nSeg, chunkIn = metaIn.p->chunk;
+    const WaveShare ws = wave_share(metaIn.p->n);
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t produced = 0, producedS = 0;                         // wave-uniform
+    uint32_t seg = ws.begin < ws.end ? seg_first(off, nSeg, ws.begin) : 0;
 #ifdef FRAY_STAMPS
     stamp_begin();
 #endif
-    for (uint32_t base = begin; base < end; base += 64u) {
+    for (uint32_t base = ws.begin; base < ws.end; base += 64u) {
         const uint32_t di = base + lane;
         bool cont = false, shadow = false;
         V3 sa, sb;
         C3 sc;
         PathState ps;
-        uint32_t i = 0;
-        bool live = di < end;
-        if (live) {
-            i = seg_lookup(sOff, nSegIn, chunkIn, di);
-            live = Qin.depthFlags[i] != FRAY_DEAD;
-        }
+        bool live = di < ws.end;
+        const uint32_t i = seg_map(off, nSeg, chunkIn, base, di, live, seg);
+        if (live) live = Qin.depthFlags[i] != FRAY_DEAD;
         if (live) {
             path_load_ray(Qin, i, ps);
             STAMP(0);
@@ -425,95 +513,55 @@ static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DSc
             closest_hit<ST>(S, ps.o, ps.d, h, c);
             path_load_rest(Qin, i, ps);
             STAMP(8);
-            if (h.node <= -2) {                                       // main.cpp:201-208
-                C3 add = (ps.flags & RF_DIFFUSE) ? c3(0, 0, 0) : light_color(S.lights[-2 - h.node]) * ps.pm;
-                path_finish(sampleRad, st, ps, add, SB);
-            } else if (h.node < 0) {                                  // main.cpp:210-215
-                path_finish(sampleRad, st, ps, environment<ST>(S, ps.d, c) * ps.pm, SB);
-            } else {
-                const FRAY_RO DNode& N = S.nodes[h.node];
-                const FRAY_RO DShader& sh = S.shaders[N.shader];
-                HitInfo info;
-                finalize_hit<ST>(S, h, ps.o, ps.d, sh.usesUV || N.bumpTex >= 0, info);
-                apply_bump<ST>(S, h.node, info, c);
-                STAMP(9);
-                mt_skip(ps.tab, spawn_words(sh));                     // the discarded spawnRay (main.cpp:219-224)
-                shadow = nee_prepare(S, ps.d, info, ps.pm, sh, ps.rnd, ps.tab, sa, sb, sc);
-                STAMP(10);
-                PathRay win, wout;
-                win.o = ps.o; win.d = ps.d; win.depth = ps.depth; win.flags = ps.flags;
-                C3 brdf;
-                float pdf;
-                spawn_ray(sh, info, win, ps.tab, wout, brdf, pdf);
-                STAMP(11);
-                if (pdf == -1.0f) {
-                    path_finish(sampleRad, st, ps, c3(1, 0, 0), SB);
-                } else if (pdf == 0.0f) {
-                    path_finish(sampleRad, st, ps, c3(0, 0, 0), SB);
-                } else {
-                    ps.pm = ps.pm * brdf / pdf;
-                    ps.o = wout.o; ps.d = wout.d; ps.depth = wout.depth; ps.flags = wout.flags;
-                    // entry test of the next pathtrace() call (main.cpp:173-176)
-                    if (ps.depth > S.maxTraceDepth || intensity(ps.pm) < 0.01) path_finish(sampleRad, st, ps, c3(0, 0, 0), SB);
-                    else cont = true;
-                }
-            }
+            path_shade<ST, false>(S, ps, h, sampleRad, st, SB, cont, shadow, sa, sb, sc, c);
+            STAMP(10);
         }
-        STAMP(12);
-        const unsigned long long mask = __ballot(cont);
-        if (cont) path_store(Qout, begin + produced + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), ps);
-        produced += (uint32_t)__popcll(mask);
-        const unsigned long long smask = __ballot(shadow);
-        if (shadow) {
-            const uint32_t j = begin + producedS + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull));
-            SQ.ax[j] = sa.x; SQ.ay[j] = sa.y; SQ.az[j] = sa.z;
-            SQ.bx[j] = sb.x; SQ.by[j] = sb.y; SQ.bz[j] = sb.z;
-            SQ.cr[j] = sc.r; SQ.cg[j] = sc.g; SQ.cb[j] = sc.b;
-            SQ.slot[j] = ps.slot;
-        }
-        producedS += (uint32_t)__popcll(smask);
+        bounce_emit(Qout, SQ, ws.begin, produced, producedS, cont, shadow, ps, sa, sb, sc);
         STAMP(13);
     }
 #ifdef FRAY_STAMPS
     if (lane < 16) atomicAdd(&st->stamp[lane], g_stampAcc[threadIdx.x >> 6][lane]);
 #endif
-    if (lane == 0) { metaOut->cnt[w] = produced; metaShadow->cnt[w] = producedS; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { metaOut->chunk = chunk; metaOut->nSeg = W; metaShadow->chunk = chunk; metaShadow->nSeg = W; }
+    if (lane == 0) { metaOut->cnt[ws.w] = produced; metaShadow->cnt[ws.w] = producedS; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { metaOut->chunk = ws.chunk; metaOut->nSeg = ws.W; metaShadow->chunk = ws.chunk; metaShadow->nSeg = ws.W; }
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
 
-// visible() for every queued next-event segment (main.cpp:64-80, 143-144); the survivor's radiance is
-// added to its sample.  One segment per sample per bounce, so the read-modify-write has no contender.
+// visible() for every queued next-event segment (main.cpp:64-80, 143-144); the unobstructed ones add their
+// radiance to their sample.  One segment per sample per bounce, so the read-modify-write has no contender.
 template <int ST>
-static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(DScene S, ShadowQueue SQ, const QMeta* __restrict__ meta,
-                                                                        float* __restrict__ sampleRad, DStats* st)
+static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(DScene S, ShadowQueue SQ, QMetaRO meta, float* __restrict__ sampleRad, DStats* st)
 {
-    __shared__ uint32_t sOff[FRAY_MAXSEG + 1];
     Cnt c = zero_cnt();
-    const uint32_t n = meta->n, nSeg = meta->nSeg, chunkIn = meta->chunk;
-    for (uint32_t k = threadIdx.x; k <= nSeg; k += blockDim.x) sOff[k] = meta->off[k];
-    __syncthreads();
+    const FRAY_RO uint32_t* off = meta.p->off;
+    const uint32_t nSeg = meta.p->nSeg, chunkIn = meta.p->chunk;
+    const WaveShare ws = wave_share(meta.p->n);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (ws.begin >= ws.end) return;
+    uint32_t seg = seg_first(off, nSeg, ws.begin);
 #ifdef FRAY_STAMPS
     stamp_begin();
 #endif
-    for (uint32_t di = blockIdx.x * blockDim.x + threadIdx.x; di < n; di += gridDim.x * blockDim.x) {
-        const uint32_t i = seg_lookup(sOff, nSeg, chunkIn, di);
-        V3 a = v3(SQ.ax[i], SQ.ay[i], SQ.az[i]), b = v3(SQ.bx[i], SQ.by[i], SQ.bz[i]);
-        STAMP(0);
-        const bool vis = visible<ST>(S, a, b, c);
-        STAMP(6);
-        if (vis) {
-            C3 add = c3(SQ.cr[i], SQ.cg[i], SQ.cb[i]);
-            if (add.r != 0 || add.g != 0 || add.b != 0) {
-                size_t q = (size_t)SQ.slot[i] * 3;
-                sampleRad[q] += add.r; sampleRad[q + 1] += add.g; sampleRad[q + 2] += add.b;
+    for (uint32_t base = ws.begin; base < ws.end; base += 64u) {
+        const uint32_t di = base + lane;
+        const bool live = di < ws.end;
+        const uint32_t i = seg_map(off, nSeg, chunkIn, base, di, live, seg);
+        if (live) {
+            const V3 a = v3(SQ.ax[i], SQ.ay[i], SQ.az[i]), b = v3(SQ.bx[i], SQ.by[i], SQ.bz[i]);
+            STAMP(0);
+            if (visible<ST>(S, a, b, c)) {
+                C3 add = c3(SQ.cr[i], SQ.cg[i], SQ.cb[i]);
+                if (add.r != 0 || add.g != 0 || add.b != 0) {
+                    size_t q = (size_t)SQ.slot[i] * 3;
+                    sampleRad[q] += add.r; sampleRad[q + 1] += add.g; sampleRad[q + 2] += add.b;
+                }
             }
         }
         STAMP(13);
     }
 #ifdef FRAY_STAMPS
-    if ((threadIdx.x & 63) < 16) atomicAdd(&st->stamp[threadIdx.x & 63], g_stampAcc[threadIdx.x >> 6][threadIdx.x & 63]);
+    if (lane < 16) atomicAdd(&st->stamp[lane], g_stampAcc[threadIdx.x >> 6][lane]);
 #endif
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);

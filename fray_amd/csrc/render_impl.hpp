@@ -178,16 +178,19 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     hipLaunchKernelGGL(k_pt_init<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, ls, S, C, F, nItems, s0, cn, L.Q[0],
                                        rad, L.x397, L.SB, eye, sc->d_stats);
                     for (int b = 0; b < nBounce; b++) {
+                        const QMetaRO mIn{(const FRAY_RO QMeta*)(L.meta + (b & 1))}, mSh{(const FRAY_RO QMeta*)(L.meta + 2)};
+                        const int grid = bounce_grid((size_t)nItems * cn);
                         hipEvent_t ea = pool_event(sc->evPool, nTraceEvents), eb = pool_event(sc->evPool, nTraceEvents + 1);
+                        hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
+                        if (!ea || !eb || !ec || !ed) return FRAYHIP_E_NOMEM;
                         HIP_TRY(hipEventRecord(ea, ls));
-                        hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(bounce_grid((size_t)nItems * cn)), dim3(256), 0, ls, S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ,
-                                           L.meta + (b & 1), L.meta + ((b + 1) & 1), L.meta + 2, rad, save, sc->d_stats);
+                        hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(grid), dim3(256), 0, ls, S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ,
+                                           mIn, L.meta + ((b + 1) & 1), L.meta + 2, rad, save, sc->d_stats);
                         HIP_TRY(hipEventRecord(eb, ls));
                         nTraceEvents += 2;
                         hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, ls, L.meta + ((b + 1) & 1), L.meta + 2);
-                        hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
                         HIP_TRY(hipEventRecord(ec, ls));
-                        hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, ls, S, L.SQ, L.meta + 2, rad, sc->d_stats + 1);
+                        hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid), dim3(256), 0, ls, S, L.SQ, mSh, rad, sc->d_stats + 1);
                         HIP_TRY(hipEventRecord(ed, ls));
                         nShadowEvents += 2;
                     }
@@ -212,8 +215,8 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
 #ifdef FRAY_STAMPS
     {
         static const char* names[16] = {"queue lookup + ray load", "local ray (transform)", "root box test", "tree-less triangle loop", "-", "other geometry (plane/sphere/KD)",
-                                        "node finish + compare", "lights", "load rest of path", "finalize hit + bump", "discarded spawn + NEE prepare", "spawn ray",
-                                        "throughput + finish", "queue stores", "-", "-"};
+                                        "phase B: results + merge", "lights", "load rest of path", "-", "shading (finalize .. spawn)", "-",
+                                        "phase A: store to LDS", "phase C / queue stores", "phase B: list build", "phase B: gather + local ray"};
         for (int q = 0; q < 2; q++) {
             double tot = 0;
             for (int k = 0; k < 16; k++) tot += (double)dsv[q].stamp[k];

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define FRAYHIP_ABI_VERSION 1
+#define FRAYHIP_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------------------------ */
 enum {

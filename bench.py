@@ -279,14 +279,40 @@ def main():
             check = bool(torch.equal(whole, frame))
         dist.barrier()
 
+    # Per-kernel launch durations for the roofline.  In the timed region up to four batches of a path-traced frame
+    # overlap on four streams, so a launch's event-to-event duration there includes the time it shared the chip
+    # (the durations sum to more than the frame).  The roofline therefore takes its durations from a second, SERIALISED
+    # pass of the same frames (one batch lane: every launch alone on the chip, HIP events around each launch on the
+    # stream it runs on) -- the same mode the kept rocprofv3 kernel trace under profiles/ is collected in.
+    serial = None
+    if rank == 0 and world == 1 and scene.settings.gi:
+        scene.set_option("pt_lanes", 1)
+        step()
+        torch.cuda.synchronize()
+        n_ser = max(1, min(args.steps, 3))
+        t1 = time.perf_counter()
+        acc = {"ms_trace": 0.0, "trace_launches": 0, "ms_shadow": 0.0, "shadow_launches": 0, "ms_kernels": 0.0}
+        for _ in range(n_ser):
+            st = step()
+            for k in acc:
+                acc[k] += st[k]
+        torch.cuda.synchronize()
+        serial = {k: v / n_ser for k, v in acc.items()}
+        serial["ms_per_step"] = (time.perf_counter() - t1) * 1e3 / n_ser
+        scene.set_option("pt_lanes", 4)
+
     if rank == 0:
-        # roofline of the dominant kernel on rank 0: algorithmic bytes (SURVEY 8d byte model, from the
-        # counters of this rank's share) / that kernel's launch time measured with HIP events
-        alg_bytes_rank0 = st_counts["alg_bytes_trace"]
-        avg_launch_ms = trace_ms / max(1, trace_launches)
-        bytes_per_launch = alg_bytes_rank0 * args.steps / max(1, trace_launches)
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        from tools.source_hash import source_hash
+        src = source_hash()
         kern = {abi.MODE_PRIMARY_ID: "k_primary"}.get(mode, "k_pt_bounce" if scene.settings.gi else "k_whitted")
+        # launch durations: serialised pass for path tracing, the timed region itself otherwise (one kernel, one stream)
+        tr_ms = serial["ms_trace"] if serial else trace_ms / args.steps
+        tr_n = serial["trace_launches"] if serial else trace_launches / args.steps
+        avg_launch_ms = tr_ms / max(1, tr_n)
+        flops_per_launch = st_counts["alg_flops_trace"] / max(1, tr_n)
+        bytes_per_launch = st_counts["alg_bytes_trace"] / max(1, tr_n)
+        tf = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+        FP64_PEAK = 39.3        # TFLOP/s: MI355X vector FP64 78.6 TFLOP/s counts an FMA as two; the reference arithmetic has no FMA (one operation per lane per issue)
         out = {
             "metric": "Mrays/s (closest-hit + shadow rays) at %dx%d, %dspp %s" % (
                 W, H, scene.samples_per_pixel(),
@@ -304,72 +330,51 @@ def main():
                        "rays_per_frame": rays_total, "camera_samples_per_frame": float(counts[2]),
                        "parallelism": "tiles%d" % world if world > 1 else "single-gpu",
                        "frame_ms": ms_per_step, "msamples_per_s": float(counts[2]) / (ms_per_step * 1e-3) / 1e6},
-            "roofline": {"bound": "hbm", "kernel": kern, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
-                         "alg_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms,
-                         "launches_per_step": trace_launches / args.steps,
-                         "note": "algorithmic bytes per SURVEY 8(d); scene tables are L2/LDS resident, so this is not HBM traffic"},
+            # What bounds the dominant kernel is FP64 vector issue, not HBM: algorithmic FP64
+            # operations per launch (SURVEY 8d operation counts x this frame's work counters) / average launch duration.
+            "roofline": {"bound": "fp64_valu", "kernel": kern, "achieved": tf, "peak": FP64_PEAK, "unit": "TFLOP/s", "frac": tf / FP64_PEAK,
+                         "alg_flops_per_launch": flops_per_launch, "avg_launch_ms": avg_launch_ms, "launches_per_step": tr_n,
+                         "sum_launch_ms_per_step": tr_ms,
+                         "durations_from": ("serialised pass (pt_lanes = 1), %.2f ms per frame" % serial["ms_per_step"]) if serial else "the timed region",
+                         "traffic": None, "counters": None, "source_hash": src},
+            # The contract's HBM figure: SURVEY 8(d) algorithmic bytes over the same durations.  Those bytes are node transforms and
+            # triangle records served by the scalar cache / L2 (the scene is a few KB), so this is NOT a DRAM rate and may exceed the peak.
+            "roofline_hbm": {"bound": "hbm", "kernel": kern, "achieved": bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0,
+                             "peak": 8000.0, "unit": "GB/s", "alg_bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_launch_ms,
+                             "note": "algorithmic bytes per SURVEY 8(d), cache-served; measured HBM traffic is roofline.traffic"},
             "kernel_ms_per_step": kernels_ms / args.steps,
             "launch_ms_sums_per_step": {"trace": trace_ms / args.steps, "shadow": shadow_ms / args.steps,
-                                        "launches": [trace_launches / args.steps, shadow_launches / args.steps]},
+                                        "launches": [trace_launches / args.steps, shadow_launches / args.steps],
+                                        "note": "timed region; launches of up to four batch lanes overlap, so these sums exceed ms_per_step"},
         }
-        if shadow_launches and kernels_ms > 0:
-            # Path-tracing batches run on several streams at once, so the launches of different batches overlap and a
-            # launch's event-to-event duration includes the time it shared the chip (the durations sum to more than the
-            # frame).  `achieved` above is the contract's figure (bytes per launch / average launch duration, the same
-            # average rocprofv3 reports); this is the same byte count over the kernel's share of the frame's wall time.
-            share = trace_ms / (trace_ms + shadow_ms)
-            excl_ms = kernels_ms * share / max(1, trace_launches)
-            out["roofline"]["achieved_exclusive"] = bytes_per_launch / (excl_ms * 1e-3) / 1e9
-            out["roofline"]["avg_launch_ms_exclusive"] = excl_ms
-            out["roofline"]["concurrency_note"] = ("launches of up to 4 batches overlap on 4 streams; *_exclusive = this kernel's "
-                                                   "share (by summed launch time) of the frame's wall time per launch")
-        if shadow_launches:
-            sb = st_counts["alg_bytes_shadow"] * args.steps / shadow_launches
-            sms = shadow_ms / shadow_launches
-            out["roofline_shadow_kernel"] = {"bound": "hbm", "kernel": "k_pt_shadow", "achieved": sb / (sms * 1e-3) / 1e9, "peak": 8000.0,
-                                             "unit": "GB/s", "frac": sb / (sms * 1e-3) / 1e9 / 8000.0, "alg_bytes_per_launch": sb,
-                                             "avg_launch_ms": sms, "launches_per_step": shadow_launches / args.steps}
-        # FP64 rate beside the byte rate.  Operation counts per test are the survey's
-        # (Node::intersect ~90, triangle ~45, box ~30 FP64 operations); the reference build has no FMA,
-        # so the ceiling for this arithmetic is one operation per lane per issue: half of the 78.6 TFLOP/s
-        # (FMA = 2) vector FP64 peak.  Rank 0's share over the frame time.
-        try:
-            ops = (90.0 * st_counts["node_tests"] + 45.0 * st_counts["tri_tests"] + 30.0 * st_counts["prim_tests"] +
-                   30.0 * (st_counts["node_tests"] + 2.0 * st_counts["kd_inner_visits"]))
-            tf = ops / (ms_per_step * 1e-3) / 1e12
-            out["fp64"] = {"achieved": tf, "peak": 39.3, "unit": "TFLOP/s", "frac": tf / 39.3,
-                           "note": "algorithmic FP64 operations (survey's per-test counts) / frame time; peak = vector FP64 without FMA (78.6 / 2)"}
-        except KeyError:
-            pass
+        out["roofline_hbm"]["frac"] = out["roofline_hbm"]["achieved"] / 8000.0
+        if serial and serial["shadow_launches"]:
+            sms = serial["ms_shadow"] / serial["shadow_launches"]
+            sf = st_counts["alg_flops_shadow"] / serial["shadow_launches"]
+            out["roofline_shadow_kernel"] = {"bound": "fp64_valu", "kernel": "k_pt_shadow", "achieved": sf / (sms * 1e-3) / 1e12, "peak": FP64_PEAK, "unit": "TFLOP/s",
+                                             "frac": sf / (sms * 1e-3) / 1e12 / FP64_PEAK, "alg_flops_per_launch": sf, "avg_launch_ms": sms,
+                                             "launches_per_step": serial["shadow_launches"], "sum_launch_ms_per_step": serial["ms_shadow"],
+                                             "alg_bytes_per_launch": st_counts["alg_bytes_shadow"] / serial["shadow_launches"]}
         if check is not None:
             out["gathered_frame_equals_single_rank_frame"] = check
-        # HBM traffic of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
-        # separate runs of this same command; profiles/pmc_traffic_latest.json)
-        tr_path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-        if world == 1 and args.workload == "cornell_pt64" and os.path.exists(tr_path):
+        # Counter-derived figures (HBM traffic, VALU issue and lane utilisation) cannot be collected by this process: they come
+        # from rocprofv3 --pmc passes of this same command (tools/profile_headline.sh -> profiles/pmc_latest.json) and are printed
+        # only when that profile was taken on the same device code (source hash) and workload; otherwise they stay null.
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if world == 1 and os.path.exists(pmc_path):
             try:
-                tr = json.load(open(tr_path))["void k_pt_bounce<0>"]
-                f_kb = tr["FETCH_SIZE"]["total"] / tr["FETCH_SIZE"]["launches"]
-                w_kb = tr["WRITE_SIZE"]["total"] / tr["WRITE_SIZE"]["launches"]
-                out["roofline"]["traffic"] = (f_kb + w_kb) * 1024.0
-                out["roofline"]["traffic_gb_per_s"] = (f_kb + w_kb) * 1024.0 / (avg_launch_ms * 1e-3) / 1e9
-                out["roofline"]["traffic_frac_of_hbm_peak"] = out["roofline"]["traffic_gb_per_s"] / 8000.0
-                out["roofline"]["traffic_note"] = ("rocprofv3 --pmc, per launch: FETCH_SIZE %.3g KB (raw; gfx950 may under-count wide reads by up to 2x) + "
-                                                   "WRITE_SIZE %.3g KB" % (f_kb, w_kb))
-            except (KeyError, ValueError, ZeroDivisionError):
-                pass
-        # what actually bounds the kernel: FP64 VALU issue.  Static figures from the SQ
-        # counter passes of this same command (tools/pmc_sq.sh -> profiles/r01_f_sq_counters.json).
-        sq_path = os.path.join(ROOT, "profiles", "r01_f_sq_counters.json")
-        if world == 1 and args.workload == "cornell_pt64" and os.path.exists(sq_path):
-            try:
-                sq = json.load(open(sq_path))
-                out["roofline"]["valu"] = {k: {"valu_busy": sq[n]["derived"]["valu_busy"], "lane_utilisation": sq[n]["derived"]["lane_utilisation"]}
-                                           for k, n in (("k_pt_bounce", "void k_pt_bounce<0>"), ("k_pt_shadow", "void k_pt_shadow<0>"))}
-                out["roofline"]["valu"]["note"] = ("rocprofv3 --pmc SQ_ACTIVE_INST_VALU x4 / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs); "
-                                                   "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)")
-            except (KeyError, ValueError):
+                pmc = json.load(open(pmc_path))
+                if pmc.get("source_hash") == src and pmc.get("workload") == args.workload:
+                    for key, kname in (("roofline", kern), ("roofline_shadow_kernel", "k_pt_shadow")):
+                        k = pmc["kernels"].get(kname)
+                        if k and key in out:
+                            out[key]["traffic"] = k.get("hbm_bytes_per_launch")
+                            out[key]["traffic_note"] = k.get("hbm_note")
+                            out[key]["counters"] = k.get("derived")
+                            out[key]["profile_avg_launch_ms"] = k.get("avg_launch_ms")
+                else:
+                    out["roofline"]["counters_note"] = "profiles/pmc_latest.json is for source %s / %s: not this build" % (pmc.get("source_hash"), pmc.get("workload"))
+            except (KeyError, ValueError, OSError):
                 pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(fray_amd, abi, wl, args.seed, gpu_frame=frame.cpu().numpy()) if mode == abi.MODE_RENDER else None

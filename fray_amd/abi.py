@@ -136,7 +136,8 @@ class Stats(C.Structure):
                 ("texture_fetches", u64),
                 ("ms_total", f64), ("ms_kernels", f64), ("ms_trace", f64),
                 ("trace_launches", u64), ("alg_bytes_trace", f64),
-                ("ms_shadow", f64), ("shadow_launches", u64), ("alg_bytes_shadow", f64)]
+                ("ms_shadow", f64), ("shadow_launches", u64), ("alg_bytes_shadow", f64),
+                ("alg_flops_trace", f64), ("alg_flops_shadow", f64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

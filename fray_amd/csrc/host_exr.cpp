@@ -316,8 +316,10 @@ void decode(const std::vector<unsigned char>& file, Image& img)
     if (ch.empty() || x1 < x0 || y1 < y0) throw ExrError("missing channels / dataWindow");
     if (compression != 0 && compression != 4) throw ExrError("only NONE and PIZ compression are supported");
     if (lineOrder > 1) throw ExrError("unsupported line order");
-    const int W = x1 - x0 + 1, H = y1 - y0 + 1;
-    if (W > 8192 || H > 8192) throw ExrError("image too large");
+    // in 64 bits: x1 - x0 + 1 of two arbitrary int32 corners does not fit an int
+    const int64_t W64 = (int64_t)x1 - (int64_t)x0 + 1, H64 = (int64_t)y1 - (int64_t)y0 + 1;
+    if (W64 <= 0 || H64 <= 0 || W64 > 8192 || H64 > 8192) throw ExrError("image too large");
+    const int W = (int)W64, H = (int)H64;
     const int lines = compression == 4 ? 32 : 1;
     const int nChunks = (H + lines - 1) / lines;
     std::vector<uint64_t> offsets(nChunks);
@@ -327,13 +329,14 @@ void decode(const std::vector<unsigned char>& file, Image& img)
     img.w = W; img.h = H;
     img.rgb.assign((size_t)W * H * 3, 0.0f);
     for (int k = 0; k < nChunks; k++) {
-        if (offsets[k] + 8 > file.size()) throw ExrError("bad chunk offset");
+        if (offsets[k] > file.size() || file.size() - offsets[k] < 8) throw ExrError("bad chunk offset");   // no `offset + 8`: that wraps for offsets near 2^64
         Reader c{file.data() + offsets[k], file.data() + file.size()};
         int y = c.i32(), size = c.i32();
         if (size < 0) throw ExrError("bad chunk size");
         c.need((size_t)size);
-        int yb = y - y0;
-        if (yb < 0 || yb >= H || yb % lines) throw ExrError("bad chunk row");
+        const int64_t yb64 = (int64_t)y - (int64_t)y0;
+        if (yb64 < 0 || yb64 >= H || yb64 % lines) throw ExrError("bad chunk row");
+        const int yb = (int)yb64;
         int ny = std::min(lines, H - yb);
         std::vector<uint16_t> raw;
         if (compression == 4 && (size_t)size < wordsPerLine * ny * 2) {

@@ -227,8 +227,9 @@ bool load_obj(const char* path, MeshData& mesh)
     mesh.vertices.assign(3, 0.0);
     mesh.uvs.assign(3, 0.0);
     mesh.normals.assign(3, 0.0);
-    static char line[10000];
-    while (fgets(line, sizeof line, f)) {
+    std::vector<char> lineBuf(10000);      // per call: scenes may be parsed from different threads (include/frayhip.h)
+    char* const line = lineBuf.data();
+    while (fgets(line, (int)lineBuf.size(), f)) {
         if (line[0] == '#') continue;
         std::vector<std::string> tok = words(line);
         if (tok.empty()) continue;
@@ -334,12 +335,15 @@ bool load_bmp(const char* path, Image& img, std::string& err)
         fseek(fp, 0, SEEK_END);
         long size = ftell(fp);
         fseek(fp, here, SEEK_SET);
-        long rowBytes = ((long)w * (bpp / 8) + 3) / 4 * 4;
-        if (imgOffset < 54 || imgOffset > size || rowBytes > (size - imgOffset) + 4) { err = "file is shorter than its header claims"; return false; }
+        long long rowBytes = ((long long)w * (bpp / 8) + 3) / 4 * 4;
+        // every row the header promises must be in the file (the last row may lack its padding): a 100 KB file that claims
+        // 32768 x 32768 pixels must not drive a 12.9 GB allocation
+        if (imgOffset < 54 || imgOffset > size || rowBytes * (long long)h > (long long)(size - imgOffset) + 4) { err = "file is shorter than its header claims"; return false; }
     }
-    float palette[256][3];
+    float palette[256][3] = {};
     int toread = 0;
     if (bpp <= 8) {
+        if (colors < 0) { err = "bad palette size"; return false; }
         toread = colors ? colors : (1 << bpp);
         if (toread > 256) { err = "bad palette size"; return false; }
         for (int i = 0; i < toread; i++) {

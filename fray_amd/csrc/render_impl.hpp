@@ -259,6 +259,12 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
         o.ms_shadow = sumEvents(sc->evPoolShadow, nShadowEvents);
         o.shadow_launches = nShadowEvents / 2;
         o.alg_bytes_shadow = model(b);
+        // SURVEY 8(d) operation counts: Node::intersect ~90, triangle test ~45, primitive ~30, box test ~30 (one per node, two per inner KD node)
+        auto flops = [](const DStats& d) {
+            return 90.0 * (double)d.node + 45.0 * (double)d.tri + 30.0 * (double)d.prim + 30.0 * ((double)d.node + 2.0 * (double)d.kdInner);
+        };
+        o.alg_flops_trace = flops(a);
+        o.alg_flops_shadow = flops(b);
         o.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         *st = o;
     }

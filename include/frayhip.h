@@ -236,6 +236,10 @@ typedef struct frayhip_stats {
     double   ms_shadow;          /* device time inside k_pt_shadow                           */
     uint64_t shadow_launches;
     double   alg_bytes_shadow;   /* byte model of the shadow-ray kernel                      */
+    /* algorithmic FP64 operations of the same launches (Node::intersect ~90, triangle test
+       ~45, box test ~30, primitive ~30 operations each), for the FP64-issue roofline      */
+    double   alg_flops_trace;
+    double   alg_flops_shadow;
 } frayhip_stats;
 
 /* ---- host scene layer (stands behind Scene::parseScene + Scene::beginRender,

@@ -274,3 +274,78 @@ def test_malformed_assets_fail_cleanly_or_fall_back_to_the_dummy_element(fray, t
     files = {"env/%s.exr" % f: bytes(exr) for f in ("negx", "negy", "negz", "posx", "posy", "posz")}
     s = parse(fray, tmp_path, BASE + 'CubemapEnvironment e {\n\tfolder "env"\n}\n', files)
     assert s.desc.environment.present == 1 and s.desc.environment.loaded == 0
+
+
+def test_loaders_under_address_and_ub_sanitizers(tmp_path):
+    """The host loaders (EXR / PIZ, BMP, OBJ + KD build, .fray) built with -fsanitize=address,undefined and fed the shipped
+    assets, truncations and bit flips of them, and the hand-made headers that used to overflow: a chunk offset of
+    2^64 - 4 (offset + 8 wrapped), a dataWindow whose width overflows int32, a BMP that claims 32768 x 32768 pixels in
+    a few hundred bytes, an 8-bit BMP with a negative colour count."""
+    import random
+    import shutil
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    exe = tmp_path / "san_loaders"
+    src = [os.path.join(root, "tests", "native", "san_loaders.cpp")] + [os.path.join(root, "fray_amd", "csrc", f)
+                                                                        for f in ("host_scene.cpp", "host_loaders.cpp", "host_exr.cpp")]
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "fray_amd", "csrc")] + src + ["-o", str(exe)], check=True)
+    rnd = random.Random(7)
+    corpus = []
+
+    def put(name, data):
+        f = tmp_path / name
+        f.write_bytes(data)
+        corpus.append(str(f))
+
+    exr = open(os.path.join(root, "scenes", "env", "forest", "posx.exr"), "rb").read()
+    put("good.exr", exr)
+    # header geometry of this file: locate the dataWindow attribute and the chunk offset table behind the header's end
+    dw = exr.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+    hdr_end = exr.index(b"\0\0", exr.index(b"lineOrder")) if b"lineOrder" in exr else 0
+    bad = bytearray(exr)
+    bad[dw:dw + 16] = struct.pack("<iiii", -2147483648, 0, 2147483647, 255)          # x1 - x0 + 1 overflows int32
+    put("window_overflow.exr", bytes(bad))
+    bad = bytearray(exr)
+    bad[dw:dw + 16] = struct.pack("<iiii", 0, -2147483648, 255, 2147483647)
+    put("window_overflow_y.exr", bytes(bad))
+    # every 8-byte little-endian word that equals a plausible chunk offset becomes 2^64 - 4 in turn (the table sits right after the header)
+    first_chunk = min(o for o in (struct.unpack_from("<Q", exr, k)[0] for k in range(300, 600, 1)) if 300 < o < len(exr))
+    table = next(k for k in range(300, 600) if struct.unpack_from("<Q", exr, k)[0] == first_chunk)
+    for j in range(3):
+        bad = bytearray(exr)
+        bad[table + 8 * j:table + 8 * j + 8] = struct.pack("<Q", 2 ** 64 - 4 - j)
+        put("offset_wrap_%d.exr" % j, bytes(bad))
+    for j in range(40):                                                              # truncations and bit flips
+        bad = bytearray(exr[:rnd.randrange(8, len(exr))]) if j % 2 else bytearray(exr)
+        for _ in range(rnd.randrange(1, 6)):
+            bad[rnd.randrange(len(bad))] ^= 1 << rnd.randrange(8)
+        put("fuzz_%02d.exr" % j, bytes(bad))
+    good = bmp24(4, 4, lambda x, y: (x * 60, y * 60, 0))
+    put("good.bmp", good)
+    lying = bytearray(good)
+    lying[22:26] = struct.pack("<i", 32768)
+    lying[18:22] = struct.pack("<i", 1)                                               # one row fits, 32768 rows do not
+    put("lying_height.bmp", bytes(lying))
+    pal = bytearray(good)
+    pal[28:30] = struct.pack("<H", 8)
+    pal[46:50] = struct.pack("<i", -5)                                               # negative colour count
+    put("negative_colours.bmp", bytes(pal))
+    pal[46:50] = struct.pack("<i", 0)
+    put("short_palette.bmp", bytes(pal))
+    for j in range(20):
+        bad = bytearray(good)
+        for _ in range(rnd.randrange(1, 5)):
+            bad[rnd.randrange(len(bad))] = rnd.randrange(256)
+        put("fuzz_%02d.bmp" % j, bytes(bad))
+    put("odd.obj", b"v 0 0 0\nv 1 0 0\nv 0 1 0\nvn\nvt 1\nf 1 2 3\nf 1 2 99\nf -4 2 3\nf 1/7/9 2 3\nf\nf 1\n" + b"v " + b"9" * 12000 + b"\n")
+    shutil.copy(os.path.join(root, "scenes", "geom", "heart.obj"), tmp_path / "heart.obj")
+    corpus.append(str(tmp_path / "heart.obj"))
+    r = subprocess.run([str(exe)] + corpus, capture_output=True, text=True, timeout=300,
+                       env={**os.environ, "ASAN_OPTIONS": "detect_leaks=0:allocator_may_return_null=1", "UBSAN_OPTIONS": "print_stacktrace=1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = dict((os.path.basename(l.split()[1]), l.split()[0]) for l in r.stdout.splitlines() if l)
+    assert lines["good.exr"] == "loaded" and lines["good.bmp"] == "loaded" and lines["heart.obj"] == "loaded"
+    for name in ("window_overflow.exr", "window_overflow_y.exr", "offset_wrap_0.exr", "offset_wrap_1.exr", "offset_wrap_2.exr",
+                 "lying_height.bmp", "negative_colours.bmp"):
+        assert lines[name] == "rejected", name

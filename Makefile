@@ -16,10 +16,10 @@ HOST_OBJ := $(HOST_SRC:.cpp=.o)
 # render_variant.hip is compiled once per kernel flag word (render_impl<0..3>): four independent translation
 # units that `make -j` builds side by side
 VARIANT_OBJ := $(foreach st,0 1 2 3,fray_amd/csrc/variant$(st).o)
-HIP_OBJ  := fray_amd/csrc/capi.o $(VARIANT_OBJ)
+HIP_OBJ  := fray_amd/csrc/capi.o fray_amd/csrc/capi_comm.o $(VARIANT_OBJ)
 HIP_HDR  := $(wildcard fray_amd/csrc/*.h) $(wildcard fray_amd/csrc/*.hpp) include/frayhip.h
 
-all: fray_amd/libfrayhip.so oracle/libfray_oracle.so examples/fray_render ref
+all: fray_amd/libfrayhip.so oracle/libfray_oracle.so examples/fray_render examples/fray_render_mgpu ref
 
 fray_amd/csrc/%.o: fray_amd/csrc/%.cpp $(HIP_HDR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
@@ -33,7 +33,7 @@ fray_amd/csrc/variant%.o: fray_amd/csrc/render_variant.hip $(HIP_HDR)
 	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -DFRAY_ST=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> fray_amd/csrc/variant$*.resources.txt || (cat fray_amd/csrc/variant$*.resources.txt; false)
 
 fray_amd/libfrayhip.so: $(HOST_OBJ) $(HIP_OBJ)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl
 
 oracle/libfray_oracle.so: oracle/fray_oracle.cpp include/frayhip.h
 	$(CXX) $(CXXFLAGS) -shared -pthread -o $@ $<
@@ -41,6 +41,10 @@ oracle/libfray_oracle.so: oracle/fray_oracle.cpp include/frayhip.h
 # C++ host example over the C ABI (no Python, no torch)
 examples/fray_render: examples/fray_render.cpp include/frayhip.h fray_amd/libfrayhip.so
 	$(CXX) -O2 -std=c++17 -Iinclude $< -o $@ -Lfray_amd -lfrayhip -Wl,-rpath,'$$ORIGIN/../fray_amd' -Wl,-rpath,/opt/rocm/lib
+
+# the multi-GPU frame from C++: one process per GPU, frayhip_gather_buckets (RCCL) as the exchange step
+examples/fray_render_mgpu: examples/fray_render_mgpu.cpp include/frayhip.h fray_amd/libfrayhip.so
+	$(CXX) -O2 -std=c++17 -Iinclude -I/opt/rocm/include $< -o $@ -Lfray_amd -lfrayhip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../fray_amd' -Wl,-rpath,/opt/rocm/lib
 
 # Partial reference build: only when the reference tree is mounted (never on the GPU box).
 ref:
@@ -50,7 +54,7 @@ resources: $(VARIANT_OBJ)
 	python3 tools/kernel_resources.py fray_amd/csrc/variant*.resources.txt
 
 clean:
-	rm -f fray_amd/csrc/*.o fray_amd/csrc/*.resources.txt fray_amd/libfrayhip.so oracle/libfray_oracle.so examples/fray_render
+	rm -f fray_amd/csrc/*.o fray_amd/csrc/*.resources.txt fray_amd/libfrayhip.so oracle/libfray_oracle.so examples/fray_render examples/fray_render_mgpu
 	rm -rf oracle/_ref
 
 .PHONY: all ref clean resources

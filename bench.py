@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--spp-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="N > 1: also render the whole frame on rank 0 and require the gathered frame to equal it")
+    ap.add_argument("--torch-gather", action="store_true", help="N > 1: exchange through torch.distributed.gather instead of frayhip_gather_buckets")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the real multi-GPU run) or gloo (rehearsal: N ranks sharing GPU 0)")
     args = ap.parse_args()
 
@@ -201,10 +202,32 @@ def main():
     dists = torch.zeros((H, W), dtype=torch.float64, device=dev) if mode == abi.MODE_PRIMARY_ID else None
     lib = fray_amd.lib
     from fray_amd import tiles
-    gatherer = tiles.TileGather(W, H, 3, rank, world, dev, dist, stage_host=(args.backend != "nccl")) if world > 1 else None
-    # hit-record frames gather the same way: int32 ids as one 4-byte channel, f64 distances as two
-    gather_ids = tiles.TileGather(W, H, 1, rank, world, dev, dist, stage_host=(args.backend != "nccl")) if world > 1 and ids is not None else None
-    gather_dist = tiles.TileGather(W, H, 2, rank, world, dev, dist, stage_host=(args.backend != "nccl")) if world > 1 and ids is not None else None
+    # The one exchange step.  On the real multi-GPU run (--backend nccl) it happens inside the library: frayhip_gather_buckets, grouped RCCL
+    # send/recv peer -> root over xGMI.  If that cannot be set up on this host every rank falls back TOGETHER to the same step over
+    # torch.distributed, and the JSON line says which transport ran.  --backend gloo (ranks sharing one GPU) stages through the host.
+    gatherer = gather_ids = gather_dist = None
+    transport = None
+    if world > 1:
+        ok = 0
+        libgather = None
+        if args.backend == "nccl" and not args.torch_gather:
+            try:
+                libgather = tiles.LibraryGather(rank, world, dist)
+                ok = 1
+            except Exception as e:                 # noqa: BLE001 -- any failure here means "use the other transport"
+                sys.stderr.write("rank %d: library gather unavailable (%s)\n" % (rank, e))
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            gatherer = gather_ids = gather_dist = libgather
+            transport = "frayhip_gather_buckets (RCCL ncclSend/ncclRecv, peer -> root)"
+        else:
+            stage = args.backend != "nccl"
+            gatherer = tiles.TileGather(W, H, 3, rank, world, dev, dist, stage_host=stage)
+            # hit-record frames gather the same way: int32 ids as one 4-byte channel, f64 distances as two
+            gather_ids = tiles.TileGather(W, H, 1, rank, world, dev, dist, stage_host=stage) if ids is not None else None
+            gather_dist = tiles.TileGather(W, H, 2, rank, world, dev, dist, stage_host=stage) if ids is not None else None
+            transport = "torch.distributed.gather (%s)" % args.backend
     rdev = dev if args.backend == "nccl" else torch.device("cpu")     # where small reduction tensors live
 
     def stream_ptr():
@@ -357,6 +380,8 @@ def main():
                                              "alg_bytes_per_launch": st_counts["alg_bytes_shadow"] / serial["shadow_launches"]}
         if check is not None:
             out["gathered_frame_equals_single_rank_frame"] = check
+        if transport:
+            out["config"]["gather"] = transport
         # Counter-derived figures (HBM traffic, VALU issue and lane utilisation) cannot be collected by this process: they come
         # from rocprofv3 --pmc passes of this same command (tools/profile_headline.sh -> profiles/pmc_latest.json) and are printed
         # only when that profile was taken on the same device code (source hash) and workload; otherwise they stay null.

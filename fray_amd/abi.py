@@ -167,6 +167,11 @@ SYMBOLS = {
     "frayhip_bucket_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "frayhip_pack_buckets_device": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "frayhip_unpack_buckets_device": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "frayhip_comm_unique_id": (C.c_int, [VP]),
+    "frayhip_comm_create": (C.c_int, [VP, C.c_int, C.c_int, P(VP)]),
+    "frayhip_comm_from_nccl": (C.c_int, [VP, C.c_int, C.c_int, P(VP)]),
+    "frayhip_comm_destroy": (None, [VP]),
+    "frayhip_gather_buckets": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "frayhip_to_rgb32": (C.c_int, [VP, VP, C.c_int]),
     "frayhip_save_bmp": (C.c_int, [C.c_char_p, VP, C.c_int, C.c_int]),
     "frayhip_debug_rng": (C.c_int, [u32, C.c_int, VP, VP, VP, C.c_int]),

@@ -1,0 +1,189 @@
+// C ABI, multi-GPU exchange step: the buckets every rank rendered are gathered into rank `root`'s frame
+// with direct peer -> root transfers over xGMI -- one grouped ncclRecv per peer on the root, one ncclSend on every
+// other rank (RCCL; no ring: with seven point-to-point links per GPU the seven peers send concurrently on seven
+// links) -- between a pack and an unpack kernel (dev_pack.hpp).  Stands behind what the reference's render() does
+// when its bucket threads have all written the one shared `vfb` (src/main.cpp:360,404).
+//
+// RCCL is bound at run time (dlopen), so the library loads on hosts without it and a process that already holds an
+// RCCL (PyTorch brings its own copy under the same soname) keeps exactly one.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "render_state.hpp"
+#include "dev_pack.hpp"
+
+namespace {
+
+using frayhip_detail::set_error;
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+
+Rccl* rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) { r.why = std::string("RCCL is not available: ") + dlerror(); return; }
+        auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p) r.why = std::string("RCCL lacks ") + n; return p; };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    });
+    return r.why.empty() ? &r : nullptr;
+}
+
+int grid_for_items(size_t n)
+{
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace
+
+struct frayhip_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    bool owned = true;
+    float* d_stage = nullptr;       // root: one packed block per peer, back to back; other ranks: this rank's packed buckets
+    size_t stage_floats = 0;
+};
+
+#define NCCL_TRY(expr)                                                                                          \
+    do {                                                                                                        \
+        ncclResult_t r_ = (expr);                                                                               \
+        if (r_ != ncclSuccess) { set_error(std::string(#expr) + ": " + R->GetErrorString(r_)); return FRAYHIP_E_HIP; } \
+    } while (0)
+
+extern "C" {
+
+int frayhip_comm_unique_id(void* id128)
+{
+    if (!id128) { set_error("frayhip_comm_unique_id: null argument"); return FRAYHIP_E_ARG; }
+    Rccl* R = rccl();
+    if (!R) { set_error("frayhip_comm_unique_id: RCCL is not available on this host"); return FRAYHIP_E_UNSUPPORTED; }
+    static_assert(sizeof(ncclUniqueId) == FRAYHIP_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    NCCL_TRY(R->GetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return FRAYHIP_OK;
+}
+
+int frayhip_comm_create(const void* id128, int rank, int world, frayhip_comm** out)
+{
+    if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) { set_error("frayhip_comm_create: bad argument"); return FRAYHIP_E_ARG; }
+    frayhip_comm* c = new frayhip_comm();
+    c->rank = rank; c->world = world;
+    if (world > 1) {
+        Rccl* R = rccl();
+        if (!R) { delete c; set_error("frayhip_comm_create: RCCL is not available on this host"); return FRAYHIP_E_UNSUPPORTED; }
+        ncclUniqueId id;
+        memcpy(&id, id128, sizeof id);
+        ncclResult_t r = R->CommInitRank(&c->comm, world, id, rank);     // uses the calling thread's current HIP device (frayhip_init)
+        if (r != ncclSuccess) { set_error(std::string("ncclCommInitRank: ") + R->GetErrorString(r)); delete c; return FRAYHIP_E_HIP; }
+    }
+    *out = c;
+    return FRAYHIP_OK;
+}
+
+int frayhip_comm_from_nccl(void* nccl_comm, int rank, int world, frayhip_comm** out)
+{
+    if (!out || !nccl_comm || world < 1 || rank < 0 || rank >= world) { set_error("frayhip_comm_from_nccl: bad argument"); return FRAYHIP_E_ARG; }
+    if (!rccl()) { set_error("frayhip_comm_from_nccl: RCCL is not available on this host"); return FRAYHIP_E_UNSUPPORTED; }
+    frayhip_comm* c = new frayhip_comm();
+    c->comm = (ncclComm_t)nccl_comm; c->rank = rank; c->world = world; c->owned = false;
+    *out = c;
+    return FRAYHIP_OK;
+}
+
+void frayhip_comm_destroy(frayhip_comm* c)
+{
+    if (!c) return;
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->comm && c->owned) if (Rccl* R = rccl()) (void)R->CommDestroy(c->comm);
+    delete c;
+}
+
+int frayhip_gather_buckets(frayhip_comm* c, float* d_frame, int width, int height, int channels, int root, void* hip_stream)
+{
+    if (!c || !d_frame || width <= 0 || height <= 0 || channels < 1 || root < 0 || root >= c->world) { set_error("frayhip_gather_buckets: bad argument"); return FRAYHIP_E_ARG; }
+    if (c->world == 1) return FRAYHIP_OK;                     // the one rank rendered every bucket in place
+    Rccl* R = rccl();
+    if (!R) { set_error("frayhip_gather_buckets: RCCL is not available on this host"); return FRAYHIP_E_UNSUPPORTED; }
+    hipStream_t stream = (hipStream_t)hip_stream;
+    DFrame F{};
+    F.W = width; F.H = height; F.BW = (width - 1) / 48 + 1; F.BH = (height - 1) / 48 + 1;
+    F.bucketStride = c->world;
+    auto floats_of = [&](int r) { return (size_t)frayhip_bucket_count(width, height, r, c->world) * 2304 * (size_t)channels; };
+    size_t need = 0;
+    if (c->rank == root) { for (int r = 0; r < c->world; r++) if (r != root) need += floats_of(r); }
+    else need = floats_of(c->rank);
+    if (need > c->stage_floats) {
+        if (c->d_stage) (void)hipFree(c->d_stage);
+        c->d_stage = nullptr; c->stage_floats = 0;
+        if (hipMalloc((void**)&c->d_stage, need * sizeof(float)) != hipSuccess) { set_error("frayhip_gather_buckets: out of device memory for the staging buffer"); return FRAYHIP_E_NOMEM; }
+        c->stage_floats = need;
+    }
+    if (c->rank != root) {
+        const size_t n = floats_of(c->rank);
+        if (n == 0) return FRAYHIP_OK;
+        F.bucketFirst = c->rank; F.nBuckets = (int)(n / 2304 / channels);
+        const int items = F.nBuckets * 2304;
+        hipLaunchKernelGGL(k_pack, dim3(grid_for_items(items)), dim3(256), 0, stream, F, items, channels, d_frame, c->d_stage, 0);
+        HIP_TRY(hipGetLastError());
+        NCCL_TRY(R->Send(c->d_stage, n, ncclFloat, root, c->comm, stream));
+        return FRAYHIP_OK;
+    }
+    // root: every peer's block arrives concurrently (one point-to-point link each), then goes to its pixels
+    NCCL_TRY(R->GroupStart());
+    size_t off = 0;
+    for (int r = 0; r < c->world; r++) {
+        if (r == root) continue;
+        const size_t n = floats_of(r);
+        if (n) NCCL_TRY(R->Recv(c->d_stage + off, n, ncclFloat, r, c->comm, stream));
+        off += n;
+    }
+    NCCL_TRY(R->GroupEnd());
+    off = 0;
+    for (int r = 0; r < c->world; r++) {
+        if (r == root) continue;
+        const size_t n = floats_of(r);
+        if (n) {
+            F.bucketFirst = r; F.nBuckets = (int)(n / 2304 / channels);
+            const int items = F.nBuckets * 2304;
+            hipLaunchKernelGGL(k_pack, dim3(grid_for_items(items)), dim3(256), 0, stream, F, items, channels, d_frame, c->d_stage + off, 1);
+        }
+        off += n;
+    }
+    HIP_TRY(hipGetLastError());
+    return FRAYHIP_OK;
+}
+
+}  // extern "C"

@@ -1,6 +1,11 @@
 """Multi-GPU tile exchange: every rank renders the 48x48 buckets b = rank (mod world) of the
-frame; one gather of the packed buckets to rank 0 ends the frame.  torch.distributed is only the
-transport (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
+frame; one gather of the packed buckets to rank 0 ends the frame.
+
+LibraryGather  the exchange inside the C ABI (frayhip_gather_buckets: pack, grouped RCCL send/recv peer -> root over
+               xGMI, unpack); torch.distributed only carries the 128-byte communicator id to the ranks once
+TileGather     the same step with torch.distributed as the transport ("gloo" in the CPU tests and one-GPU rehearsals)"""
+import ctypes as C
+
 import torch
 
 from . import scene as _scene
@@ -27,6 +32,43 @@ def device_unpack(packed, frame, W, H, rank, world, stream=None):
         raise _scene.FrayError(rc, _scene.lib.frayhip_last_error().decode())
 
 
+def _current_stream(frame):
+    return torch.cuda.current_stream(frame.device).cuda_stream if frame.is_cuda else None
+
+
+class LibraryGather:
+    """frayhip_comm_* / frayhip_gather_buckets.  `dist` must be initialised (any backend): it broadcasts rank 0's id."""
+
+    def __init__(self, rank, world, dist, dst=0):
+        lib = _scene.lib
+        self.rank, self.world, self.dst = rank, world, dst
+        ident = [None]
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            rc = lib.frayhip_comm_unique_id(buf)
+            if rc:
+                raise _scene.FrayError(rc, lib.frayhip_last_error().decode())
+            ident = [bytes(buf)]
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        self._comm = C.c_void_p()
+        rc = lib.frayhip_comm_create(ident[0], rank, world, C.byref(self._comm))
+        if rc:
+            raise _scene.FrayError(rc, lib.frayhip_last_error().decode())
+
+    def gather(self, frame):
+        H, W, ch = frame.shape
+        rc = _scene.lib.frayhip_gather_buckets(self._comm, frame.data_ptr(), W, H, ch, self.dst, _current_stream(frame))
+        if rc:
+            raise _scene.FrayError(rc, _scene.lib.frayhip_last_error().decode())
+        return frame
+
+    def close(self):
+        if self._comm:
+            _scene.lib.frayhip_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+
+
 class TileGather:
     """Buffers and the one exchange step.  pack(frame, W, H, rank, world, out) and
     unpack(packed, frame, W, H, rank, world) default to the HIP kernels."""
@@ -43,7 +85,9 @@ class TileGather:
         """frame: [H, W, C] float32 with this rank's buckets rendered; on rank dst it is complete on return."""
         if self.world == 1:
             return frame
-        self.pack(frame, self.W, self.H, self.rank, self.world, self.packed)
+        stream = _current_stream(frame)          # the stream the frame was rendered on, not the NULL stream
+        kw = {"stream": stream} if self.pack is device_pack else {}
+        self.pack(frame, self.W, self.H, self.rank, self.world, self.packed, **kw)
         if self.stage_host:
             host = self.packed.cpu()
             got = [torch.zeros_like(host) for _ in range(self.world)] if self.rank == self.dst else None
@@ -56,5 +100,5 @@ class TileGather:
         if self.rank == self.dst:
             for r in range(self.world):
                 if r != self.dst:
-                    self.unpack(self.recv[r], frame, self.W, self.H, r, self.world)
+                    self.unpack(self.recv[r], frame, self.W, self.H, r, self.world, **({"stream": stream} if self.unpack is device_unpack else {}))
         return frame

@@ -303,6 +303,24 @@ int  frayhip_pack_buckets_device(const float* d_frame, float* d_packed, int widt
 int  frayhip_unpack_buckets_device(const float* d_packed, float* d_frame, int width, int height,
                                    int channels, int bucket_first, int bucket_stride, void* hip_stream);
 
+/* The exchange itself, inside the library: rank r (of `world`) has rendered the buckets b with b % world == r into
+ * its own full-size device frame (frayhip_frame.bucket_first = r, bucket_stride = world); frayhip_gather_buckets
+ * moves every other rank's buckets into rank `root`'s frame -- pack, direct peer -> root RCCL transfers over xGMI
+ * (grouped ncclRecv on the root, one ncclSend per peer), unpack -- enqueued on `hip_stream` of each rank.  Collective:
+ * every rank of the communicator calls it.  One process per GPU; frayhip_init(device) first.
+ *   frayhip_comm_unique_id   rank 0 obtains the 128-byte ncclUniqueId and hands it to the other ranks by whatever
+ *                            means the host has (MPI, a file, torch.distributed, a socket)
+ *   frayhip_comm_create      every rank, with the same id; world == 1 needs no id and no RCCL
+ *   frayhip_comm_from_nccl   wraps an ncclComm_t the host already owns (not destroyed by frayhip_comm_destroy)
+ * RCCL is bound at run time: FRAYHIP_E_UNSUPPORTED when the host has none. */
+#define FRAYHIP_COMM_ID_BYTES 128
+typedef struct frayhip_comm frayhip_comm;
+int  frayhip_comm_unique_id(void* id128);
+int  frayhip_comm_create(const void* id128, int rank, int world, frayhip_comm** out);
+int  frayhip_comm_from_nccl(void* nccl_comm, int rank, int world, frayhip_comm** out);
+void frayhip_comm_destroy(frayhip_comm* c);
+int  frayhip_gather_buckets(frayhip_comm* c, float* d_frame, int width, int height, int channels, int root, void* hip_stream);
+
 /* vfb -> RGB32 with clamp, no gamma (displayVFB, sdl.cpp:63-74; Color::toRGB32, color.h:59-65). */
 int  frayhip_to_rgb32(const float* rgb, uint32_t* out, int n_pixels);
 

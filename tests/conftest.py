@@ -12,6 +12,38 @@ SCENES = os.path.join(ROOT, "scenes")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    # A clean launcher for tests that start other programs (torch.distributed.run + bench.py): the fork server is started now,
+    # before anything in this process has touched the GPU, and children are forked from IT -- a process that has initialised
+    # the GPU must not fork + exec other programs on this pool.
+    import multiprocessing
+    from multiprocessing import forkserver
+    try:
+        multiprocessing.get_context("forkserver")
+        forkserver.ensure_running()
+    except (ValueError, OSError):
+        pass
+
+
+def _run_command(cmd, cwd, env, out_path, timeout):
+    import subprocess
+    with open(out_path, "w") as f:
+        try:
+            r = subprocess.run(cmd, cwd=cwd, env=env, stdout=f, stderr=subprocess.STDOUT, timeout=timeout)
+            f.write("\n[exit code %d]\n" % r.returncode)
+        except subprocess.TimeoutExpired:
+            f.write("\n[timed out]\n")
+
+
+def run_in_clean_child(cmd, out_path, timeout=600, env=None):
+    """Runs `cmd` as a child of the fork server started in pytest_configure (not of this process); returns its output."""
+    import multiprocessing
+    ctx = multiprocessing.get_context("forkserver")
+    p = ctx.Process(target=_run_command, args=(cmd, ROOT, dict(env or os.environ), out_path, timeout))
+    p.start()
+    p.join(timeout + 30)
+    if p.is_alive():
+        p.terminate()
+    return open(out_path).read() if os.path.exists(out_path) else ""
 
 
 @pytest.fixture(scope="session")

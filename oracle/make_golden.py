@@ -36,7 +36,30 @@ CASES = [
     ("nonconvex_aa", "hw9/nonconvex.fray", 48, 36, "wantAA=1", 3, 200),
     ("csg_nested", "../tests/scenes/csg_nested.fray", 60, 45, "wantAA=0", 2, 400),       # this repository's scene: CsgOp trees three levels deep
     ("fuzz1009_pt", "../tests/scenes/fuzz1009/scene.fray", 76, 32, "gi=1;numPaths=4", 2, 400),   # a generated scene that caught a path-tracing mismatch
+    # forest with its cubemap LOADED: the reference's CubemapEnvironment::loadMaps / getEnvironment object code (environment.cpp:31-98)
+    # on the faces this project's EXR decoder produced (handed to oracle/ref_glue.cpp's Bitmap::loadEXR as plain texel files)
+    ("forest_env_whitted", "forest.fray", 64, 40, "wantAA=0", 3, 300),
+    ("forest_env_dof", "forest.fray", 48, 30, "wantAA=0;dof=1;numDOFSamples=6", 5, 0),
 ]
+ENV_LOADED = {"forest_env_whitted", "forest_env_dof"}
+
+
+def dump_faces(scene, folder):
+    """The cubemap faces of `scene` as this project's host layer decoded them -> <folder>/<face>.exr.f32 (int32 w, h; float32 RGB rows)."""
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("FRAYHIP_NO_TORCH", "1")
+    import fray_amd
+    s = fray_amd.Scene.parseScene(os.path.join(ROOT, "scenes", scene))
+    e = s.desc.environment
+    assert e.present and e.loaded, "the scene has no decodable cubemap"
+    tex = np.ctypeslib.as_array(s.desc.texels, shape=(s.desc.n_texels,))
+    for f, name in enumerate(("negx", "negy", "negz", "posx", "posy", "posz")):
+        w, h = e.width[f], e.height[f]
+        with open(os.path.join(folder, name + ".exr.f32"), "wb") as out:
+            out.write(np.array([w, h], np.int32).tobytes())
+            out.write(np.ascontiguousarray(tex[e.texel_offset[f]:e.texel_offset[f] + w * h * 3], np.float32).tobytes())
+    s.close()
+
 
 
 def worker(name, scene, W, H, over, stride, nrand):
@@ -77,7 +100,7 @@ def worker(name, scene, W, H, over, stride, nrand):
     img = np.zeros((H, W, 3), np.float32)
     lib.ref_render(img.ctypes.data, 42)
     np.savez_compressed(os.path.join(OUT, "ref_%s.npz" % name), scene=scene, W=W, H=H, overrides=over, seed=42,
-                        ray_start=S, ray_dir=D, hit_id=ids, hit_rec=rec, image=img)
+                        ray_start=S, ray_dir=D, hit_id=ids, hit_rec=rec, image=img, env_loaded=int(name in ENV_LOADED))
     print(name, "rays", len(rays), "hits", int((ids != -1).sum()), "image mean %.4f" % img.mean(), flush=True)
 
 
@@ -91,4 +114,11 @@ if __name__ == "__main__":
         for c in CASES:
             if only and c[0] not in only:
                 continue
-            subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(x) for x in c], check=True)
+            env = dict(os.environ)
+            env.pop("FRAY_REF_FACES_DIR", None)
+            if c[0] in ENV_LOADED:
+                import tempfile
+                faces = tempfile.mkdtemp(prefix="fray_faces_")
+                dump_faces(c[1], faces)
+                env["FRAY_REF_FACES_DIR"] = faces
+            subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(x) for x in c], check=True, env=env)

@@ -11,7 +11,7 @@
 //   frameWidth/frameHeight            (sdl.cpp)      -> values set by the harness
 //   Random::*, getRandomGen           (random_generator.cpp) -> the same libstdc++ calls; one
 //                                      generator plays the per-thread table entry
-//   Bitmap::*                         (bitmap.cpp)   -> own BMP reader, no EXR
+//   Bitmap::*                         (bitmap.cpp)   -> own BMP reader; EXR faces only as pre-decoded texel files (Bitmap::loadEXR below)
 //   visible, raytrace, hemisphereSample (+ pathtrace, the frame loop)   (main.cpp) -> restated
 // So what this library pins is everything the compiled files own: the .fray parser, transforms,
 // OBJ loading, the KD build and walk, every geometry / light / camera / shader / texture method.
@@ -133,12 +133,39 @@ bool Bitmap::loadBMP(const char* filename)
     return ok;
 }
 bool Bitmap::saveBMP(const char*) { return false; }
-bool Bitmap::loadEXR(const char*) { return false; }   // OpenEXR is absent: cubemaps stay unloaded in _ref
+// OpenEXR is absent, so bitmap.cpp:238-264 cannot be built.  When FRAY_REF_FACES_DIR is set, an .exr name is served
+// from <dir>/<basename>.f32 instead: {int32 w, int32 h, w*h*3 float32 RGB, rows top to bottom} -- the texels
+// oracle/make_golden.py dumped from this project's own EXR decoder.  That does NOT pin the decoder; it lets the
+// reference's CubemapEnvironment::loadMaps / getEnvironment object code (environment.cpp:31-98) run on those texels.
+bool Bitmap::loadEXR(const char* filename)
+{
+    freeMem();
+    const char* dir = getenv("FRAY_REF_FACES_DIR");
+    if (!dir) return false;
+    const char* base = strrchr(filename, '/');
+    std::string path = std::string(dir) + "/" + (base ? base + 1 : filename) + ".f32";
+    FILE* fp = fopen(path.c_str(), "rb");
+    if (!fp) return false;
+    int wh[2] = {0, 0};
+    bool ok = fread(wh, 4, 2, fp) == 2 && wh[0] > 0 && wh[1] > 0 && wh[0] <= 8192 && wh[1] <= 8192;
+    if (ok) {
+        generateEmptyImage(wh[0], wh[1]);
+        std::vector<float> row((size_t)wh[0] * 3);
+        for (int y = 0; y < wh[1] && ok; y++) {
+            ok = fread(row.data(), 4, row.size(), fp) == row.size();
+            for (int x = 0; x < wh[0] && ok; x++) data[x + y * width] = Color(row[3 * x], row[3 * x + 1], row[3 * x + 2]);
+        }
+    }
+    fclose(fp);
+    if (!ok) freeMem();
+    return ok;
+}
 bool Bitmap::saveEXR(const char*) { return false; }
 bool Bitmap::loadImage(const char* fn)
 {
     size_t l = strlen(fn);
     if (l > 4 && (!strcmp(fn + l - 4, ".bmp") || !strcmp(fn + l - 4, ".BMP"))) return loadBMP(fn);
+    if (l > 4 && (!strcmp(fn + l - 4, ".exr") || !strcmp(fn + l - 4, ".EXR"))) return loadEXR(fn);   // bitmap.cpp:286-298
     return false;
 }
 bool Bitmap::saveImage(const char*) { return false; }

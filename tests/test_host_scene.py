@@ -247,6 +247,12 @@ def test_exr_piz_cubemap_decodes(fray, oracle):
         # natural image: neighbouring rows are strongly correlated, and far smoother than shuffled data
         assert np.corrcoef(img[100, :, 1], img[101, :, 1])[0, 1] > 0.7
         assert np.abs(np.diff(img, axis=0)).mean() < 0.5 * np.abs(img - np.roll(img, 97, axis=0)).mean()
+    # regression pins of the decoded texels (oracle/make_exr_hashes.py): a decoder change that moves a single bit of a face fails here
+    import json
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "exr_face_hashes.json")))["forest.fray"]
+    for f in range(6):
+        face = np.ascontiguousarray(tex[e.texel_offset[f]:e.texel_offset[f] + 256 * 256 * 3])
+        assert oracle.fnv(face) == pins[f]["fnv"], pins[f]["face"]
     # the sky face is the brightest, the ground face the darkest
     means = [float(tex[e.texel_offset[f]:e.texel_offset[f] + 256 * 256 * 3].mean()) for f in range(6)]
     assert max(range(6), key=lambda f: means[f]) == 4 and min(range(6), key=lambda f: means[f]) == 1   # POSY / NEGY

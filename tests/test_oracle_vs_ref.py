@@ -20,8 +20,9 @@ def load_case(fray, path):
         k, v = kv.split("=")
         over[k] = float(v) if "." in v else int(v)
     s = open_scene(fray, str(z["scene"]), int(z["W"]), int(z["H"]), **over)
-    if s.desc.environment.present:
-        s.desc.environment.loaded = 0        # _ref has no EXR reader: its cubemap stays unloaded (misses are black)
+    if s.desc.environment.present and not ("env_loaded" in z.files and int(z["env_loaded"])):
+        s.desc.environment.loaded = 0        # _ref has no EXR reader: unless the fixture was made with the decoded faces handed over
+                                             # (oracle/make_golden.py ENV_LOADED) its cubemap stays unloaded and misses are black
     return z, s
 
 

@@ -210,6 +210,7 @@ std::string validate_desc(const frayhip_scene_desc& d)
     for (int i = 0; i < d.n_textures; i++) {
         const frayhip_texture& t = d.textures[i];
         if (t.kind < 0 || t.kind > 3) return bad("unknown texture kind", i);
+        if ((t.kind == FRAYHIP_TEX_BITMAP || t.kind == FRAYHIP_TEX_BUMP) && (t.width <= 0 || t.height <= 0)) return bad("bitmap texture without texels", i);   // the lookup wraps modulo width / height
         if ((t.kind == FRAYHIP_TEX_BITMAP || t.kind == FRAYHIP_TEX_BUMP) && !texel_range_ok(t.texel_offset, t.width, t.height)) return bad("texture texels outside the pool", i);
     }
     for (int i = 0; i < d.n_layers; i++) {
@@ -612,18 +613,22 @@ int frayhip_render(frayhip_scene* s, const frayhip_frame* f, float* rgb, int32_t
     if (!rc && hit_id && hipMalloc((void**)&d_id, n * 4) != hipSuccess) rc = FRAYHIP_E_NOMEM;
     if (!rc && hit_dist && hipMalloc((void**)&d_dist, n * 8) != hipSuccess) rc = FRAYHIP_E_NOMEM;
     if (rc) { set_error("frayhip_render: hipMalloc failed"); cleanup(); return rc; }
-    // pixels outside this call's buckets keep what the caller had in the buffers
+    // pixels outside this call's buckets keep what the caller had in the buffers: only a call that renders a SUBSET of the
+    // buckets needs the caller's frame on the device first; a whole-frame call overwrites every pixel
     hipError_t ce = hipSuccess;
-    if (d_rgb && ce == hipSuccess) ce = hipMemcpy(d_rgb, rgb, n * 12, hipMemcpyHostToDevice);
-    if (d_id && ce == hipSuccess) ce = hipMemcpy(d_id, hit_id, n * 4, hipMemcpyHostToDevice);
-    if (d_dist && ce == hipSuccess) ce = hipMemcpy(d_dist, hit_dist, n * 8, hipMemcpyHostToDevice);
-    if (ce != hipSuccess) { set_error(std::string("frayhip_render: host-to-device copy failed: ") + hipGetErrorString(ce)); cleanup(); return FRAYHIP_E_NODEVICE; }
+    const bool subset = f->bucket_stride > 1 || f->bucket_first != 0;
+    if (subset) {
+        if (d_rgb && ce == hipSuccess) ce = hipMemcpy(d_rgb, rgb, n * 12, hipMemcpyHostToDevice);
+        if (d_id && ce == hipSuccess) ce = hipMemcpy(d_id, hit_id, n * 4, hipMemcpyHostToDevice);
+        if (d_dist && ce == hipSuccess) ce = hipMemcpy(d_dist, hit_dist, n * 8, hipMemcpyHostToDevice);
+    }
+    if (ce != hipSuccess) { set_error(std::string("frayhip_render: host-to-device copy failed: ") + hipGetErrorString(ce)); cleanup(); return frayhip_detail::hip_error_code(ce); }
     rc = frayhip_render_device(s, f, d_rgb, d_id, d_dist, nullptr, st);
     if (!rc) {
         if (d_rgb && ce == hipSuccess) ce = hipMemcpy(rgb, d_rgb, n * 12, hipMemcpyDeviceToHost);
         if (d_id && ce == hipSuccess) ce = hipMemcpy(hit_id, d_id, n * 4, hipMemcpyDeviceToHost);
         if (d_dist && ce == hipSuccess) ce = hipMemcpy(hit_dist, d_dist, n * 8, hipMemcpyDeviceToHost);
-        if (ce != hipSuccess) { set_error(std::string("frayhip_render: device-to-host copy failed: ") + hipGetErrorString(ce)); rc = FRAYHIP_E_NODEVICE; }
+        if (ce != hipSuccess) { set_error(std::string("frayhip_render: device-to-host copy failed: ") + hipGetErrorString(ce)); rc = frayhip_detail::hip_error_code(ce); }
     }
     cleanup();
     return rc;
@@ -644,17 +649,17 @@ __global__ void k_debug_rng(uint32_t seed, int n, float* f, double* d, int32_t* 
 int frayhip_debug_rng(uint32_t seed, int n, float* floats, double* doubles, int32_t* ints, int int_hi)
 {
     if (n < 0 || n > 4096 || int_hi < 0) { set_error("frayhip_debug_rng: bad argument"); return FRAYHIP_E_ARG; }
-    float* df = nullptr; double* dd = nullptr; int32_t* di = nullptr; uint32_t* work = nullptr;
-    HIP_TRY(hipMalloc((void**)&df, 4096 * 4));
-    HIP_TRY(hipMalloc((void**)&dd, 4096 * 8));
-    HIP_TRY(hipMalloc((void**)&di, 4096 * 4));
-    HIP_TRY(hipMalloc((void**)&work, 3 * 624 * 4));
-    hipLaunchKernelGGL(k_debug_rng, dim3(1), dim3(64), 0, nullptr, seed, n, df, dd, di, int_hi, work);
-    HIP_TRY(hipDeviceSynchronize());
-    if (floats) HIP_TRY(hipMemcpy(floats, df, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (doubles) HIP_TRY(hipMemcpy(doubles, dd, (size_t)n * 8, hipMemcpyDeviceToHost));
-    if (ints) HIP_TRY(hipMemcpy(ints, di, (size_t)n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(df); (void)hipFree(dd); (void)hipFree(di); (void)hipFree(work);
+    // one allocation: floats | doubles | ints | three 624-word generator states
+    unsigned char* buf = nullptr;
+    const size_t oF = 0, oD = 4096 * 4, oI = oD + 4096 * 8, oW = oI + 4096 * 4, total = oW + 3 * 624 * 4;
+    HIP_TRY(hipMalloc((void**)&buf, total));
+    hipLaunchKernelGGL(k_debug_rng, dim3(1), dim3(64), 0, nullptr, seed, n, (float*)(buf + oF), (double*)(buf + oD), (int32_t*)(buf + oI), int_hi, (uint32_t*)(buf + oW));
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && floats) e = hipMemcpy(floats, buf + oF, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && doubles) e = hipMemcpy(doubles, buf + oD, (size_t)n * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && ints) e = hipMemcpy(ints, buf + oI, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(buf);
+    if (e != hipSuccess) { set_error(std::string("frayhip_debug_rng: ") + hipGetErrorString(e)); return frayhip_detail::hip_error_code(e); }
     return FRAYHIP_OK;
 }
 

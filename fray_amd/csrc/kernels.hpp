@@ -102,6 +102,20 @@ FD void dof_ray(const DCamera& C, double x, double y, G& tab, V3& o, V3& d, int 
     d = normalized(T - o);
 }
 
+// maxTraceDepth < 0: raytrace() / pathtrace() return black before they look at the scene (main.cpp:173-176, 248), every pixel of the frame is 0
+static __global__ __launch_bounds__(256) void k_black(DFrame F, int nItems, int eyes, float* __restrict__ rgb, DStats* st)
+{
+    unsigned long long n = 0;
+    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < nItems; item += gridDim.x * blockDim.x) {
+        int x, y;
+        if (!item_pixel(F, item, x, y)) continue;
+        size_t p = ((size_t)y * F.W + x) * 3;
+        rgb[p] = 0; rgb[p + 1] = 0; rgb[p + 2] = 0;
+        n += (unsigned long long)(F.spp * eyes);
+    }
+    if (n) atomicAdd(&st->samples, n);
+}
+
 // ---- mt19937 seeding for a batch of camera samples -------------------------------------------------
 // x397[s * nItems + item] = x[397] of the seeding recurrence started at the contract seed of
 // (pixel(item), sample s0 + s).  The recurrence is a 397-long dependency chain of

@@ -75,6 +75,9 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     S.saturation = set.saturation;
     DCamera C = camera_begin_frame(sc->camera, W, H);
 
+    // An early (error) return below must not leave work in flight on the side lanes' streams, which the caller cannot see: whatever
+    // was enqueued is drained before the call returns.
+    struct Drain { bool armed = true; ~Drain() { if (armed) (void)hipDeviceSynchronize(); } } drain;
     HIP_TRY(hipMemsetAsync(sc->d_stats, 0, kStatsBytes, stream));
     DCursors* cursors = (DCursors*)((unsigned char*)sc->d_stats + kCursorOffset);
     HIP_TRY(hipEventRecord(sc->evA, stream));
@@ -90,7 +93,9 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
         }
     } else if (f->mode == FRAYHIP_MODE_RENDER) {
         if (!d_rgb) { set_error("frayhip_render: MODE_RENDER needs an rgb buffer"); return FRAYHIP_E_ARG; }
-        if (!set.gi) {
+        if (set.maxTraceDepth < 0) {
+            if (nItems > 0) hipLaunchKernelGGL(k_black, dim3(grid_for(nItems)), dim3(256), 0, stream, F, nItems, sc->camera.stereoSeparation > 0 ? 2 : 1, d_rgb, sc->d_stats);
+        } else if (!set.gi) {
             if (!F.jitter && spp > 5) { set_error("frayhip_render: bad sample count"); return FRAYHIP_E_ARG; }
             if (nItems > 0) {
                 // workspace: per-thread mt19937 state columns for samples that draw more than 227 words,
@@ -210,6 +215,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sc->evB, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    drain.armed = false;                    // every lane was joined into `stream` above
     DStats dsv[2];
     HIP_TRY(hipMemcpy(dsv, sc->d_stats, sizeof dsv, hipMemcpyDeviceToHost));
 #ifdef FRAY_STAMPS

@@ -593,3 +593,16 @@ def test_device_libm_vs_glibc(fray, gpu):
         exact = float((u == 0).mean())
         print("%s: identical to glibc in %.2f %% of %d calls, max %d ulp" % (name, 100 * exact, n, int(u[~near_zero].max())))
         assert exact > 0.5, (name, exact)
+
+
+@pytest.mark.parametrize("gi", [0, 1])
+def test_negative_trace_depth_is_a_black_frame(fray, abi, oracle, gpu, gi):
+    """raytrace() / pathtrace() return black before looking at the scene when depth 0 > maxTraceDepth (main.cpp:173-176, 248)."""
+    s = open_scene(fray, "cornell_box.fray", 61, 47, gi=gi, numPaths=3, wantAA=0, maxTraceDepth=-1)
+    s.beginRender()
+    img, st = s.render(seed=42, stats=True)
+    ref, ost = oracle.render(s.desc, abi.MODE_RENDER, seed=42)
+    assert not img.any() and not ref.any()
+    assert st["samples"] == ost["samples"] == 61 * 47 * s.samples_per_pixel()
+    assert st["closest_rays"] == ost["closest_rays"] == 0
+    s.close()

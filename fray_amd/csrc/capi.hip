@@ -470,6 +470,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         putX(o.T, l.T);
         put3(o.center, l.center);
         o.area = l.area;
+        sc->lightSampleCount += l.kind == FRAYHIP_LIGHT_RECT ? l.xSubd * l.ySubd : 1;
         o.areaXsize = 1.0 / l.xSubd;
         o.areaYsize = 1.0 / l.ySubd;
     }

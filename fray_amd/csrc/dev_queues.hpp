@@ -22,6 +22,18 @@ struct ShadowQueue {
     uint32_t* slot;
 };
 
+// Whitted frames of scenes whose shaders do not recurse (Lambert / Phong / Const): what Lambert::shade / Phong::shade need from
+// visible() (shading.cpp:54-78) is queued per light sample.  N = slots x eyes entries per array; task j of entry e sits at j * N + e
+// (task-major: neighbouring pixels' segments to the same light sample are neighbours in the visibility kernel).
+struct WhittedQueue {
+    float* base;                        // [N][3] the colour that needs no visibility: light / environment / Const colour, or the ambient term
+    double* ax; double* ay; double* az; // [N] the shading point every segment of the entry starts at: ip + n * 1e-6
+    unsigned char* hit;                 // [N] 1: a Lambert / Phong surface was hit and its T segments are queued
+    double* bx; double* by; double* bz; // [T][N] the light sample
+    float* rr; float* rg; float* rb;    // [T][N] what the sample adds to its light's sum if it is visible
+    unsigned char* vis;                 // [T][N] filled by k_wh_visible
+};
+
 #ifndef FRAY_MAXSEG
 #define FRAY_MAXSEG 8192   // = 2048 blocks x 4 waves, the largest grid grid_for() returns
 #endif

@@ -174,26 +174,11 @@ static __global__ __launch_bounds__(256, FRAY_PRIMARY_WAVES) void k_primary(DSce
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
 
-// ---- Whitted (main.cpp:246-285), shaders without recursion --------------------------------------
-template <int ST, class G>
-FD C3 raytrace_flat(const DScene& S, V3 o, V3 d, G& tab, Cnt& c)
-{
-    HitRec h;
-    closest_hit<ST>(S, o, d, h, c);
-    if (h.node <= -2) return light_color(S.lights[-2 - h.node]);
-    if (h.node < 0) return environment<ST>(S, d, c);
-    const FRAY_RO DNode& N = S.nodes[h.node];
-    const FRAY_RO DShader& sh = S.shaders[N.shader];
-    HitInfo info;
-    finalize_hit<ST>(S, h, o, d, sh.usesUV || N.bumpTex >= 0, info);
-    apply_bump<ST>(S, h.node, info, c);
-    if (sh.kind == 0) return ldc(sh.color);                          // ConstantShader::shade
-    return shade_direct<ST, G>(S, sh, d, info, tab, sh.kind == 2, c);   // Lambert / Phong
-}
-
 static __constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0, 0.6}, {0.6, 0.6}};   // main.cpp:55-61
 
-template <int ST, bool REC>
+// Whitted, scenes with recursive shaders (Reflection / Refraction / Layered): raytrace() per pixel, samples in order, one lane walks
+// the whole shade() tree (dev_whitted.hpp).  Scenes without them take the wavefront path below (k_wh_shade ...).
+template <int ST>
 static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(DScene S, DCamera C, DFrame F, int nItems, float* __restrict__ rgb, uint32_t* mtWork,
                                                  const uint32_t* __restrict__ x397, DStats* st, DCursors* cur)
 {
@@ -220,8 +205,8 @@ static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(DSce
                 if (C.dof) { dof_ray(C, fx, fy, tab, ol, dl, 1); dof_ray(C, fx, fy, tab, orr, dr, 2); }
                 else { screen_ray(C, fx, fy, ol, dl, 1); screen_ray(C, fx, fy, orr, dr, 2); }
                 bump<ST>(c.samples, 2);
-                C3 cl = REC ? raytrace_full<ST, MtLong>(S, ol, dl, tab, c, ovf) : raytrace_flat<ST, MtLong>(S, ol, dl, tab, c);
-                C3 cr = REC ? raytrace_full<ST, MtLong>(S, orr, dr, tab, c, ovf) : raytrace_flat<ST, MtLong>(S, orr, dr, tab, c);
+                C3 cl = raytrace_full<ST, MtLong>(S, ol, dl, tab, c, ovf);
+                C3 cr = raytrace_full<ST, MtLong>(S, orr, dr, tab, c, ovf);
                 if (S.saturation != 1) {                      // Color::adjustSaturation, color.h:127-133
                     float ml = (cl.r + cl.g + cl.b) / 3.0f, mr = (cr.r + cr.g + cr.b) / 3.0f;
                     cl = c3(ml + (cl.r - ml) * S.saturation, ml + (cl.g - ml) * S.saturation, ml + (cl.b - ml) * S.saturation);
@@ -232,7 +217,7 @@ static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(DSce
                 V3 o, d;
                 if (C.dof) dof_ray(C, fx, fy, tab, o, d); else screen_ray(C, fx, fy, o, d);
                 bump<ST>(c.samples);
-                avg = avg + (REC ? raytrace_full<ST, MtLong>(S, o, d, tab, c, ovf) : raytrace_flat<ST, MtLong>(S, o, d, tab, c));
+                avg = avg + raytrace_full<ST, MtLong>(S, o, d, tab, c, ovf);
             }
             ovf = ovf || rnd.j > 227;
         }
@@ -243,6 +228,156 @@ static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(DSce
     }
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
+}
+
+// ---- Whitted as a wavefront, for scenes whose shaders do not recurse ---------------------------------------------
+// raytrace() (main.cpp:246-285) + Lambert::shade / Phong::shade (shading.cpp:48-144) split where they call visible():
+//   k_wh_shade    per camera sample: camera ray(s), closest hit, attributes, bump; the light loops draw every sample in the
+//                 reference's order and queue, per light sample, the segment to test and the term it would add
+//   k_wh_visible  visible() for every queued segment (the lean any-hit kernel: no shading state in registers)
+//   k_wh_gather   per camera sample: result = base + sum over lights of (sum of the visible samples' terms) / ns, the reference's
+//                 FP32 order; then k_pt_resolve sums the samples of a pixel in order
+// visible() draws no random numbers, so evaluating it after the light loops changes nothing.
+template <int ST>
+FD void wh_shade_eye(const DScene& S, V3 o, V3 d, MtLong& tab, const WhittedQueue& Q, size_t N, size_t e, Cnt& c)
+{
+    HitRec h;
+    closest_hit<ST>(S, o, d, h, c);
+    C3 base;
+    unsigned char hit = 0;
+    if (h.node <= -2) base = light_color(S.lights[-2 - h.node]);
+    else if (h.node < 0) base = environment<ST>(S, d, c);
+    else {
+        const FRAY_RO DNode& N0 = S.nodes[h.node];
+        const FRAY_RO DShader& sh = S.shaders[N0.shader];
+        HitInfo info;
+        finalize_hit<ST>(S, h, o, d, sh.usesUV || N0.bumpTex >= 0, info);
+        apply_bump<ST>(S, h.node, info, c);
+        if (sh.kind == 0) base = ldc(sh.color);                           // ConstantShader::shade
+        else {                                                            // Lambert::shade / Phong::shade up to visible()
+            const bool phong = sh.kind == 2;
+            C3 diffuse = ldc(sh.color);
+            if (sh.texture >= 0) diffuse = diffuse * texture_sample<ST>(S, sh.texture, d, info, c);
+            base = diffuse * ldc(S.ambient);
+            hit = 1;
+            const V3 n = faceforward(d, info.norm);
+            const V3 a = info.ip + n * 1e-6;
+            Q.ax[e] = a.x; Q.ay[e] = a.y; Q.az[e] = a.z;
+            size_t t = e;
+            const int nl = S.nLights;
+            for (int li = 0; li < nl; li++) {
+                const FRAY_RO DLight& L = S.lights[li];
+                const int ns = light_num_samples(L);
+                for (int k = 0; k < ns; k++, t += N) {
+                    C3 lc;
+                    V3 lp;
+                    light_nth_sample(L, k, info.ip, tab, lp, lc);
+                    double lightDistSqr = lengthSqr(info.ip - lp);
+                    V3 toLight = normalized(lp - info.ip);
+                    float cosAngle = (float)dot(toLight, n);
+                    float lambertTerm = (float)(cosAngle / lightDistSqr);
+                    lambertTerm = lambertTerm > 0.0f ? lambertTerm : 0.0f;   // max(0.0f, x)
+                    C3 r = diffuse * lc * lambertTerm;
+                    if (phong) {
+                        V3 fromLight = -toLight;
+                        V3 rr = reflect(fromLight, n);
+                        double cosCam = dot(-d, rr);
+                        if (cosCam > 0)
+                            r = r + lc / (float)lightDistSqr * ldc(sh.specularColor) * (float)pow(cosCam, sh.exponent) * (float)sh.specularMultiplier;
+                    }
+                    Q.bx[t] = lp.x; Q.by[t] = lp.y; Q.bz[t] = lp.z;
+                    Q.rr[t] = r.r; Q.rg[t] = r.g; Q.rb[t] = r.b;
+                }
+            }
+        }
+    }
+    Q.base[3 * e] = base.r; Q.base[3 * e + 1] = base.g; Q.base[3 * e + 2] = base.b;
+    Q.hit[e] = hit;
+}
+
+template <int ST>
+static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_wh_shade(DScene S, DCamera C, DFrame F, int nItems, int s0, int chunk, WhittedQueue Q, uint32_t* mtWork,
+                                                                         const uint32_t* __restrict__ x397, DStats* st)
+{
+    Cnt c = zero_cnt();
+    MtLong tab;
+    tab.stride = gridDim.x * blockDim.x;
+    tab.st = mtWork + (blockIdx.x * blockDim.x + threadIdx.x);
+    const uint32_t total = (uint32_t)nItems * (uint32_t)chunk;
+    const bool stereo = C.stereoSeparation > 0;
+    const size_t N = (size_t)total * (stereo ? 2 : 1);
+    bool ovf = false;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += gridDim.x * blockDim.x) {
+        const int item = (int)(slot % (uint32_t)nItems), s = (int)(slot / (uint32_t)nItems);
+        int x, y;
+        if (!item_pixel(F, item, x, y)) {                 // ragged edge bucket: nothing to shade, nothing to test
+            for (int eye = 0; eye < (stereo ? 2 : 1); eye++) {
+                const size_t e = (size_t)eye * total + slot;
+                Q.hit[e] = 0;
+                Q.base[3 * e] = 0; Q.base[3 * e + 1] = 0; Q.base[3 * e + 2] = 0;
+            }
+            continue;
+        }
+        const int i = s0 + s;
+        const uint32_t p = (uint32_t)y * (uint32_t)F.W + (uint32_t)x;
+        tab.reseed_with(sample_seed(F.seed, p, (uint32_t)i), x397[slot]);
+        Mt rnd = tab.r;
+        float ox, oy;
+        if (F.jitter) { ox = rng_float(rnd); oy = rng_float(rnd); }
+        else { ox = (float)kAAOffsets[i][0]; oy = (float)kAAOffsets[i][1]; }
+        const double fx = (double)((float)x + ox), fy = (double)((float)y + oy);   // int + float, main.cpp:359
+        if (stereo) {                                     // raytraceSinglePixel, main.cpp:306-317: both rays first, then left, then right
+            V3 ol, dl, orr, dr;
+            if (C.dof) { dof_ray(C, fx, fy, tab, ol, dl, 1); dof_ray(C, fx, fy, tab, orr, dr, 2); }
+            else { screen_ray(C, fx, fy, ol, dl, 1); screen_ray(C, fx, fy, orr, dr, 2); }
+            bump<ST>(c.samples, 2);
+            wh_shade_eye<ST>(S, ol, dl, tab, Q, N, slot, c);
+            wh_shade_eye<ST>(S, orr, dr, tab, Q, N, (size_t)total + slot, c);
+        } else {
+            V3 o, d;
+            if (C.dof) dof_ray(C, fx, fy, tab, o, d); else screen_ray(C, fx, fy, o, d);
+            bump<ST>(c.samples);
+            wh_shade_eye<ST>(S, o, d, tab, Q, N, slot, c);
+        }
+        ovf = ovf || rnd.j > 227;
+    }
+    if (ovf) atomicAdd(&st->rngOverflow, 1ull);
+    if (ST & 1) flush_stats(st, c);
+    if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
+}
+
+template <int ST>
+static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_wh_visible(DScene S, WhittedQueue Q, size_t N, int T, DStats* st)
+{
+    Cnt c = zero_cnt();
+    const size_t total = N * (size_t)T;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = t % N;
+        if (!Q.hit[e]) continue;
+        Q.vis[t] = visible<ST>(S, v3(Q.ax[e], Q.ay[e], Q.az[e]), v3(Q.bx[t], Q.by[t], Q.bz[t]), c) ? 1 : 0;
+    }
+    if (ST & 1) flush_stats(st, c);
+    if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
+}
+
+static __global__ __launch_bounds__(256) void k_wh_gather(DScene S, WhittedQueue Q, size_t N, size_t slots, float* __restrict__ radL, float* __restrict__ radR)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < N; e += (size_t)gridDim.x * blockDim.x) {
+        C3 result = c3(Q.base[3 * e], Q.base[3 * e + 1], Q.base[3 * e + 2]);
+        if (Q.hit[e]) {
+            size_t t = e;
+            const int nl = S.nLights;
+            for (int li = 0; li < nl; li++) {
+                const int ns = light_num_samples(S.lights[li]);
+                C3 sum = c3(0, 0, 0);
+                for (int k = 0; k < ns; k++, t += N)
+                    if (Q.vis[t]) sum = sum + c3(Q.rr[t], Q.rg[t], Q.rb[t]);
+                result = result + sum / (float)ns;
+            }
+        }
+        float* out = e < slots ? radL + 3 * e : radR + 3 * (e - slots);
+        out[0] = result.r; out[1] = result.g; out[2] = result.b;
+    }
 }
 
 // ---- path tracer (main.cpp:171-244) as a wavefront ---------------------------------------------------

@@ -97,7 +97,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             if (nItems > 0) hipLaunchKernelGGL(k_black, dim3(grid_for(nItems)), dim3(256), 0, stream, F, nItems, sc->camera.stereoSeparation > 0 ? 2 : 1, d_rgb, sc->d_stats);
         } else if (!set.gi) {
             if (!F.jitter && spp > 5) { set_error("frayhip_render: bad sample count"); return FRAYHIP_E_ARG; }
-            if (nItems > 0) {
+            if (nItems > 0 && sc->whittedNeedsRecursion) {
                 // workspace: per-thread mt19937 state columns for samples that draw more than 227 words,
                 // then x[397] of every (pixel, sample) seed
                 const int grid = persistent_grid(nItems, FRAY_WHITTED_WAVES);
@@ -107,13 +107,63 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 uint32_t* x397 = (uint32_t*)((unsigned char*)sc->d_work + colBytes);
                 hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * spp + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, 0, spp, x397);
                 hipEvent_t a = pool_event(sc->evPool, 0), b = pool_event(sc->evPool, 1);
+                if (!a || !b) return FRAYHIP_E_NOMEM;
                 HIP_TRY(hipEventRecord(a, stream));
-                if (sc->whittedNeedsRecursion)
-                    hipLaunchKernelGGL((k_whitted<ST, true>), dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats, cursors);
-                else
-                    hipLaunchKernelGGL((k_whitted<ST, false>), dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats, cursors);
+                hipLaunchKernelGGL(k_whitted<ST>, dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats, cursors);
                 HIP_TRY(hipEventRecord(b, stream));
                 nTraceEvents = 2;
+            } else if (nItems > 0) {
+                // Wavefront Whitted (no recursive shader in the scene): batches of `chunk` samples per pixel through
+                // k_wh_shade -> k_wh_visible -> k_wh_gather, then the ordered per-pixel sum (k_pt_resolve).
+                const int T = sc->lightSampleCount;
+                const bool stereo = sc->camera.stereoSeparation > 0;
+                const size_t eyes = stereo ? 2 : 1;
+                auto r256 = [](size_t b) { return (b + 255) / 256 * 256; };
+                const int grid = persistent_grid((size_t)nItems * spp, 4);
+                const size_t colBytes = r256((size_t)grid * 256 * 624 * sizeof(uint32_t));
+                // per (pixel, sample): base 12 + a 24 + hit 1 + radiance 12 per eye, 37 per light sample and eye, 4 for the seed
+                const size_t perSlot = eyes * (49 + (size_t)T * 37) + 4;
+                const size_t budget = sc->ptBudgetBytes > colBytes + (64u << 20) ? sc->ptBudgetBytes - colBytes : (64u << 20);
+                int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / ((size_t)nItems * perSlot));
+                if (chunk > spp) chunk = spp;
+                while (chunk > 1 && (size_t)nItems * chunk * eyes * (size_t)std::max(T, 1) > ((size_t)1 << 31)) chunk /= 2;
+                const size_t slots = (size_t)nItems * chunk, N = slots * eyes, NT = N * (size_t)T;
+                const size_t bytes = colBytes + r256((size_t)nItems * 12) + r256(N * 12) + 3 * r256(N * 8) + r256(N) + 3 * r256(NT * 8) + 3 * r256(NT * 4) + r256(NT) +
+                                     2 * r256(slots * 12) + r256(slots * 4) + 4096;
+                int rc = ensure_work(sc, bytes);
+                if (rc) return rc;
+                unsigned char* p = (unsigned char*)sc->d_work;
+                auto take = [&](size_t b) { unsigned char* r = p; p += r256(b); return r; };
+                uint32_t* mtWork = (uint32_t*)take(colBytes);
+                float* sum = (float*)take((size_t)nItems * 12);
+                WhittedQueue Q;
+                Q.base = (float*)take(N * 12);
+                Q.ax = (double*)take(N * 8); Q.ay = (double*)take(N * 8); Q.az = (double*)take(N * 8);
+                Q.hit = take(N);
+                Q.bx = (double*)take(NT * 8); Q.by = (double*)take(NT * 8); Q.bz = (double*)take(NT * 8);
+                Q.rr = (float*)take(NT * 4); Q.rg = (float*)take(NT * 4); Q.rb = (float*)take(NT * 4);
+                Q.vis = take(NT);
+                float* radL = (float*)take(slots * 12);
+                float* radR = (float*)take(slots * 12);
+                uint32_t* x397 = (uint32_t*)take(slots * 4);
+                for (int s0 = 0; s0 < spp; s0 += chunk) {
+                    const int cn = std::min(chunk, spp - s0);
+                    const size_t bs = (size_t)nItems * cn, bN = bs * eyes;      // this batch's slots: arrays are used with stride bN
+                    hipLaunchKernelGGL(k_seed, dim3(grid_for((bs + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
+                    hipEvent_t ea = pool_event(sc->evPool, nTraceEvents), eb = pool_event(sc->evPool, nTraceEvents + 1);
+                    hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
+                    if (!ea || !eb || !ec || !ed) return FRAYHIP_E_NOMEM;
+                    HIP_TRY(hipEventRecord(ea, stream));
+                    hipLaunchKernelGGL(k_wh_shade<ST>, dim3(grid), dim3(256), 0, stream, S, C, F, nItems, s0, cn, Q, mtWork, x397, sc->d_stats);
+                    HIP_TRY(hipEventRecord(eb, stream));
+                    nTraceEvents += 2;
+                    HIP_TRY(hipEventRecord(ec, stream));
+                    if (T > 0) hipLaunchKernelGGL(k_wh_visible<ST>, dim3(grid_for(bN * (size_t)T)), dim3(256), 0, stream, S, Q, bN, T, sc->d_stats + 1);
+                    HIP_TRY(hipEventRecord(ed, stream));
+                    nShadowEvents += 2;
+                    hipLaunchKernelGGL(k_wh_gather, dim3(grid_for(bN)), dim3(256), 0, stream, S, Q, bN, bs, radL, radR);
+                    hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, stream, F, C, set.saturation, nItems, s0, cn, radL, stereo ? radR : nullptr, sum, d_rgb);
+                }
             }
         } else if (nItems > 0) {
             if (set.maxTraceDepth > 60) { set_error("frayhip_render: maxTraceDepth above 60 is not supported"); return FRAYHIP_E_UNSUPPORTED; }

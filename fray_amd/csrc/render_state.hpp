@@ -47,6 +47,7 @@ struct frayhip_scene {
     frayhip_camera camera{};
     frayhip_settings settings{};
     bool whittedNeedsRecursion = false;
+    int lightSampleCount = 0;         // sum over lights of Light::getNumSamples(): segments a Lambert / Phong hit queues (wavefront Whitted)
     bool extGeometry = false;         // Cube / CSG nodes present
     // per-frame workspace, grown on demand and kept between frames
     void* d_work = nullptr;

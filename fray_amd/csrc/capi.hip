@@ -359,7 +359,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     size_t oCsgs = A.add(csgs.data(), csgs.size() * sizeof(DCsg));
     // meshes
     std::vector<DMesh> meshes(d.n_meshes);
-    struct MeshOff { size_t tris, attrs, kd, refs; };
+    struct MeshOff { size_t tris, attrs, kd, refs, ltris; };
     std::vector<MeshOff> moff(d.n_meshes);
     for (int mi = 0; mi < d.n_meshes; mi++) {
         const frayhip_mesh& m = d.meshes[mi];
@@ -381,7 +381,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
             put3(o.N, T.ABcrossAC);
             put3(o.AC, T.AC);
             put3(o.AB, T.AB);
-            o.pad = 0;
+            o.index = t; o.pad = 0;
             DTriAttr& a = attrs[t];
             memset(&a, 0, sizeof a);
             if (M.smooth) {
@@ -424,6 +424,9 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         moff[mi].attrs = A.add(attrs.data(), attrs.size() * sizeof(DTriAttr));
         moff[mi].kd = A.add(kd.data(), kd.size() * sizeof(DKd));
         moff[mi].refs = A.add(m.trirefs, (size_t)m.n_trirefs * sizeof(int32_t));
+        std::vector<DTri> ltris((size_t)m.n_trirefs);
+        for (int r = 0; r < m.n_trirefs; r++) ltris[r] = tris[m.trirefs[r]];
+        moff[mi].ltris = A.add(ltris.data(), ltris.size() * sizeof(DTri));
     }
     size_t oTexels = A.add(d.texels, (size_t)d.n_texels * sizeof(float));
     std::vector<DTexture> tex(d.n_textures);
@@ -491,6 +494,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         meshes[mi].attrs = (const FRAY_RO DTriAttr*)(base + moff[mi].attrs);
         meshes[mi].kd = (const FRAY_RO DKd*)(base + moff[mi].kd);
         meshes[mi].refs = (const FRAY_RO int32_t*)(base + moff[mi].refs);
+        meshes[mi].ltris = (const FRAY_RO DTri*)(base + moff[mi].ltris);
     }
     if (!meshes.empty()) memcpy(A.host.data() + oMeshes, meshes.data(), meshes.size() * sizeof(DMesh));
     for (int i = 0; i < d.n_nodes; i++) {

@@ -59,7 +59,8 @@ struct DTri {          // 128 B
     double N[3];       // AB x AC
     double AC[3];
     double AB[3];
-    double pad;
+    int32_t index;     // the triangle's index in its mesh (leaf-packed copies, DMesh::ltris, are found by position, not by index)
+    int32_t pad;
 };
 
 struct DTriAttr {      // 168 B, winning triangle only
@@ -82,6 +83,9 @@ struct DMesh {
     const FRAY_RO DTriAttr* attrs;
     const FRAY_RO DKd* kd;
     const FRAY_RO int32_t* refs;
+    // KD meshes: the triangle records again, one copy per leaf reference in leaf order (triBegin .. triBegin + triCount), so a
+    // leaf's triangles are consecutive 128-byte records instead of an index list into `tris` (one dependent load less per triangle)
+    const FRAY_RO DTri* ltris;
     int32_t nTris, hasKd, smooth, culling, hasUV, pad;
 };
 

@@ -233,10 +233,10 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
         {
             const int beg = kd[leaf].triBegin, cnt = kd[leaf].triCount;
             bool found = false;
+            const FRAY_RO DTri* lt = M.ltris + beg;
             for (int t = 0; t < cnt; t++) {
                 bump<ST>(c.leafRefs);
-                int idx = M.refs[beg + t];
-                if (tri_test<ST>(M.tris + idx, culling, s, d, gamma, l2, l3, c)) { found = true; tri = idx; }
+                if (tri_test<ST>(lt + t, culling, s, d, gamma, l2, l3, c)) { found = true; tri = lt[t].index; }
             }
             if (found && box_inside(box, s + d * gamma)) return true;
         }

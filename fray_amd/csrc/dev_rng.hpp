@@ -163,6 +163,48 @@ struct MtLong {
     }
 };
 
+// Generator of a PATH whose draws outlive one kernel and may pass 227 words (path tracing with maxTraceDepth >= 20: a Lambert bounce
+// draws ten).  While j < 227 it is the three-register stream above; the draw after that materialises the 624-word state in the path's
+// column of a global workspace (word k at col[k * stride]) and from then on the cursor is just the number of words drawn, with
+// FRAY_MT_MATERIALISED set: position = count % 624, the standard twist whenever the position wraps.  {j, a, b} is what the path queue
+// stores between bounces either way.
+#define FRAY_MT_MATERIALISED 0x80000000u
+struct MtPath {
+    Mt r;
+    uint32_t seed;      // the stream's seed (needed once, to materialise)
+    uint32_t* col;
+    size_t stride;
+    FD uint32_t& w(int k) { return col[(size_t)k * stride]; }
+    FD void twist()
+    {
+        for (int k = 0; k < 227; k++) w(k) = w(k + 397) ^ MtLong::tw(w(k), w(k + 1));
+        for (int k = 227; k < 623; k++) w(k) = w(k - 227) ^ MtLong::tw(w(k), w(k + 1));
+        w(623) = w(396) ^ MtLong::tw(w(623), w(0));
+    }
+    FD uint32_t next()
+    {
+        if (!(r.j & FRAY_MT_MATERIALISED)) {
+            if (r.j < 227) return mt_next(r);
+            uint32_t x = seed;                  // materialise: seeding recurrence, then the first twist
+            w(0) = x;
+            for (uint32_t i = 1; i < 624; i++) { x = mt_lcg(x, i); w((int)i) = x; }
+            twist();
+            r.j = 227u | FRAY_MT_MATERIALISED;
+        }
+        const uint32_t n = r.j & ~FRAY_MT_MATERIALISED;
+        const int idx = (int)(n % 624u);
+        if (idx == 0) twist();                  // n >= 624 here: the stream starts at word 227 of the first generation
+        uint32_t v = w(idx);
+        r.j = (n + 1u) | FRAY_MT_MATERIALISED;
+        v ^= v >> 11;
+        v ^= (v << 7) & 0x9d2c5680u;
+        v ^= (v << 15) & 0xefc60000u;
+        v ^= v >> 18;
+        return v;
+    }
+};
+FD void mt_skip(MtPath& g, int n) { for (int i = 0; i < n; i++) (void)g.next(); }
+
 // Per-(pixel, sample) seed of the RNG contract; the oracle applies the same function
 // (oracle/fray_oracle.cpp sample_seed).
 FD uint32_t fmix32(uint32_t h)

@@ -268,7 +268,8 @@ FD C3 shade_direct(const DScene& S, const FRAY_RO DShader& sh, V3 rayDir, const 
 }
 
 // ---- path tracing: BRDF::eval / BRDF::spawnRay ---------------------------------------------------------
-FD V3 hemisphere_sample(Mt& tab, V3 norm)   // main.cpp:92-116
+template <class G>
+FD V3 hemisphere_sample(G& tab, V3 norm)   // main.cpp:92-116
 {
     double u = rng_double(tab);
     double v = rng_double(tab);
@@ -296,7 +297,8 @@ FD int spawn_words(const FRAY_RO DShader& sh) { return sh.kind == 1 ? 4 : 0; }
 
 struct PathRay { V3 o, d; int depth; unsigned flags; };
 
-FD void spawn_ray(const FRAY_RO DShader& sh, const HitInfo& x, const PathRay& w_in, Mt& tab, PathRay& w_out, C3& brdf, float& pdf)
+template <class G>
+FD void spawn_ray(const FRAY_RO DShader& sh, const HitInfo& x, const PathRay& w_in, G& tab, PathRay& w_out, C3& brdf, float& pdf)
 {
     w_out = w_in;
     if (sh.kind == 1) {   // Lambert::spawnRay, shading.cpp:88-99
@@ -349,7 +351,8 @@ FD void spawn_ray(const FRAY_RO DShader& sh, const HitInfo& x, const PathRay& w_
 // random numbers or evaluates the BRDF happens here; the returned segment a->b and the contribution
 // go to the shadow queue, and k_pt_shadow adds `contrib` iff visible(a, b).  The reference asks
 // visible() before eval(); neither draws random numbers, so the order does not matter.
-FD bool nee_prepare(const DScene& S, V3 rayDir, const HitInfo& info, C3 pm, const FRAY_RO DShader& sh, Mt& rnd, Mt& tab, V3& a, V3& b, C3& contrib)
+template <class GR, class GT>
+FD bool nee_prepare(const DScene& S, V3 rayDir, const HitInfo& info, C3 pm, const FRAY_RO DShader& sh, GR& rnd, GT& tab, V3& a, V3& b, C3& contrib)
 {
     if (S.nLights == 0) return false;
     int lightIdx = rng_int0(rnd, S.nLights - 1);

@@ -16,6 +16,7 @@
 #include "dev_shade.hpp"
 #include "dev_whitted.hpp"
 #include "dev_queues.hpp"
+#include <type_traits>
 
 #ifndef FRAY_PRIMARY_WAVES
 #define FRAY_PRIMARY_WAVES 5
@@ -384,40 +385,51 @@ static __global__ __launch_bounds__(256) void k_wh_gather(DScene S, WhittedQueue
 // Path state, structure of arrays (one lane = one path, consecutive lanes = consecutive entries,
 // so every array is read and written fully coalesced).  80 bytes per path; radiance is accumulated in
 // the per-sample buffer (sampleRad[slot]), in bounce order, by k_pt_shadow and at termination.
-struct PathState {
+template <class G>
+struct PathStateT {
     V3 o, d;
     C3 pm;
     uint32_t slot;
     int depth;
     unsigned flags;
-    Mt rnd, tab;
+    G rnd, tab;        // Mt, or MtPath when a path may draw more than 227 words (dev_rng.hpp)
 };
+typedef PathStateT<Mt> PathState;
+FD Mt& cursor(Mt& g) { return g; }
+FD Mt& cursor(MtPath& g) { return g.r; }
+FD const Mt& cursor(const Mt& g) { return g; }
+FD const Mt& cursor(const MtPath& g) { return g.r; }
 
-FD void path_store(const PathQueue& Q, uint32_t i, const PathState& s)
+template <class G>
+FD void path_store(const PathQueue& Q, uint32_t i, const PathStateT<G>& s)
 {
     Q.ox[i] = s.o.x; Q.oy[i] = s.o.y; Q.oz[i] = s.o.z;
     Q.dx[i] = s.d.x; Q.dy[i] = s.d.y; Q.dz[i] = s.d.z;
     Q.tr[i] = s.pm.r; Q.tg[i] = s.pm.g; Q.tb[i] = s.pm.b;
     Q.slot[i] = s.slot;
     Q.depthFlags[i] = (uint32_t)s.depth | (s.flags << 16);
-    Q.rndJ[i] = s.rnd.j; Q.rndA[i] = s.rnd.a; Q.rndB[i] = s.rnd.b;
-    Q.tabJ[i] = s.tab.j; Q.tabA[i] = s.tab.a; Q.tabB[i] = s.tab.b;
+    const Mt &r = cursor(s.rnd), &t = cursor(s.tab);
+    Q.rndJ[i] = r.j; Q.rndA[i] = r.a; Q.rndB[i] = r.b;
+    Q.tabJ[i] = t.j; Q.tabA[i] = t.a; Q.tabB[i] = t.b;
 }
-FD void path_load_ray(const PathQueue& Q, uint32_t i, PathState& s)
+template <class G>
+FD void path_load_ray(const PathQueue& Q, uint32_t i, PathStateT<G>& s)
 {
     s.o = v3(Q.ox[i], Q.oy[i], Q.oz[i]);
     s.d = v3(Q.dx[i], Q.dy[i], Q.dz[i]);
 }
 // Everything but the ray: fetched after the closest-hit search so it is not live across it.
-FD void path_load_rest(const PathQueue& Q, uint32_t i, PathState& s)
+template <class G>
+FD void path_load_rest(const PathQueue& Q, uint32_t i, PathStateT<G>& s)
 {
     s.pm = c3(Q.tr[i], Q.tg[i], Q.tb[i]);
     s.slot = Q.slot[i];
     uint32_t df = Q.depthFlags[i];
     s.depth = (int)(df & 0xffffu);
     s.flags = df >> 16;
-    s.rnd.j = Q.rndJ[i]; s.rnd.a = Q.rndA[i]; s.rnd.b = Q.rndB[i];
-    s.tab.j = Q.tabJ[i]; s.tab.a = Q.tabA[i]; s.tab.b = Q.tabB[i];
+    Mt &r = cursor(s.rnd), &t = cursor(s.tab);
+    r.j = Q.rndJ[i]; r.a = Q.rndA[i]; r.b = Q.rndB[i];
+    t.j = Q.tabJ[i]; t.a = Q.tabA[i]; t.b = Q.tabB[i];
 }
 
 // ---- segmented path queues ---------------------------------------------------------------------------
@@ -489,17 +501,20 @@ FD uint32_t seg_map(const FRAY_RO uint32_t* off, uint32_t nSeg, uint32_t chunk, 
 // left path is traced, and the right path CONTINUES both random generators where the left path stopped.
 // So the left pass parks the right eye's ray and, when a left path ends, its generator cursors, per sample
 // slot; the right pass starts from those.  g[0] == nullptr: nothing to save (mono, or the right pass).
-FD void path_finish(float* __restrict__ sampleRad, DStats* st, const PathState& s, C3 add, const StereoBuf& SB)
+template <class G>
+FD void path_finish(float* __restrict__ sampleRad, DStats* st, const PathStateT<G>& s, C3 add, const StereoBuf& SB)
 {
+    const Mt &r = cursor(s.rnd), &t = cursor(s.tab);
     if (SB.g[0]) {
-        SB.g[0][s.slot] = s.rnd.j; SB.g[1][s.slot] = s.rnd.a; SB.g[2][s.slot] = s.rnd.b;
-        SB.g[3][s.slot] = s.tab.j; SB.g[4][s.slot] = s.tab.a; SB.g[5][s.slot] = s.tab.b;
+        SB.g[0][s.slot] = r.j; SB.g[1][s.slot] = r.a; SB.g[2][s.slot] = r.b;
+        SB.g[3][s.slot] = t.j; SB.g[4][s.slot] = t.a; SB.g[5][s.slot] = t.b;
     }
     if (add.r != 0 || add.g != 0 || add.b != 0) {      // x + 0 == x: nothing to do for black
         size_t q = (size_t)s.slot * 3;
         sampleRad[q] += add.r; sampleRad[q + 1] += add.g; sampleRad[q + 2] += add.b;
     }
-    if (s.rnd.j > 227 || s.tab.j > 227) atomicAdd(&st->rngOverflow, 1ull);
+    // the three-register streams end after 227 words; paths that may draw more run the MtPath variant of the bounce kernel
+    if (sizeof(G) == sizeof(Mt) && (r.j > 227 || t.j > 227)) atomicAdd(&st->rngOverflow, 1ull);
 }
 
 // Batch = nItems pixels x `chunk` samples starting at sample s0; slot = s * nItems + item.  The first
@@ -572,8 +587,8 @@ FD WaveShare wave_share(uint32_t n)
 // it; otherwise bump, the discarded spawnRay, the next-event sample (everything but its visibility query -> `shadow`
 // segment sa -> sb carrying sc), the real spawnRay, the throughput update and the entry test of the next iteration
 // (`cont`: ps is the path to continue).
-template <int ST, bool BARY>
-FD void path_shade(const DScene& S, PathState& ps, const HitRec& h, float* __restrict__ sampleRad, DStats* st, const StereoBuf& SB, bool& cont, bool& shadow,
+template <int ST, bool BARY, class G>
+FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitRec& h, float* __restrict__ sampleRad, DStats* st, const StereoBuf& SB, bool& cont, bool& shadow,
                    V3& sa, V3& sb, C3& sc, Cnt& c)
 {
     if (h.node <= -2) {                                       // main.cpp:201-208
@@ -610,8 +625,9 @@ FD void path_shade(const DScene& S, PathState& ps, const HitRec& h, float* __res
 
 // Survivors and next-event segments of one batch of 64 paths go to the wave's own segments of the output queues
 // (ballot rank, no global counter).
+template <class G>
 FD void bounce_emit(const PathQueue& Qout, const ShadowQueue& SQ, uint32_t segBegin, uint32_t& produced, uint32_t& producedS, bool cont, bool shadow,
-                    const PathState& ps, V3 sa, V3 sb, C3 sc)
+                    const PathStateT<G>& ps, V3 sa, V3 sb, C3 sc)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long mask = __ballot(cont);
@@ -631,10 +647,14 @@ FD void bounce_emit(const PathQueue& Qout, const ShadowQueue& SQ, uint32_t segBe
 // **Dominant kernel**: one pathtrace() iteration (main.cpp:171-244) for every live path of the queue: closest hit,
 // then path_shade.  Every wave owns a contiguous share of the queue's dense indices and writes its survivors and
 // next-event segments into its own segments of the output queues.
-template <int ST>
+// LONG: the generators are MtPath (paths that may draw more than 227 words, i.e. maxTraceDepth >= 20); `LR` says where a path's two
+// 624-word columns live and how to recompute its seed (slot -> pixel, sample).
+struct LongRng { uint32_t* cols; uint32_t nPaths; DFrame F; int nItems, s0; };
+template <int ST, bool LONG>
 static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, PathQueue Qin, PathQueue Qout, ShadowQueue SQ, QMetaRO metaIn,
-                                                                          QMeta* metaOut, QMeta* metaShadow, float* __restrict__ sampleRad, StereoBuf SB, DStats* st)
+                                                                          QMeta* metaOut, QMeta* metaShadow, float* __restrict__ sampleRad, StereoBuf SB, LongRng LR, DStats* st)
 {
+    typedef typename std::conditional<LONG, MtPath, Mt>::type G;
     Cnt c = zero_cnt();
     const FRAY_RO uint32_t* off = metaIn.p->off;
     const uint32_t nSeg = metaIn.p->nSeg, chunkIn = metaIn.p->chunk;
@@ -650,7 +670,7 @@ static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DSc
         bool cont = false, shadow = false;
         V3 sa, sb;
         C3 sc;
-        PathState ps;
+        PathStateT<G> ps;
         bool live = di < ws.end;
         const uint32_t i = seg_map(off, nSeg, chunkIn, base, di, live, seg);
         if (live) live = Qin.depthFlags[i] != FRAY_DEAD;
@@ -661,6 +681,15 @@ static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DSc
             HitRec h;
             closest_hit<ST>(S, ps.o, ps.d, h, c);
             path_load_rest(Qin, i, ps);
+            if constexpr (LONG) {
+                int px, py;
+                item_pixel(LR.F, (int)(ps.slot % (uint32_t)LR.nItems), px, py);
+                const uint32_t sd = sample_seed(LR.F.seed, (uint32_t)py * (uint32_t)LR.F.W + (uint32_t)px, (uint32_t)(LR.s0 + (int)(ps.slot / (uint32_t)LR.nItems)));
+                ps.rnd.seed = ps.tab.seed = sd;
+                ps.rnd.stride = ps.tab.stride = LR.nPaths;
+                ps.rnd.col = LR.cols + ps.slot;
+                ps.tab.col = LR.cols + (size_t)624 * LR.nPaths + ps.slot;
+            }
             STAMP(8);
             path_shade<ST, false>(S, ps, h, sampleRad, st, SB, cont, shadow, sa, sb, sc, c);
             STAMP(10);

@@ -166,12 +166,16 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 }
             }
         } else if (nItems > 0) {
-            if (set.maxTraceDepth > 60) { set_error("frayhip_render: maxTraceDepth above 60 is not supported"); return FRAYHIP_E_UNSUPPORTED; }
+            if (set.maxTraceDepth > 2000) { set_error("frayhip_render: maxTraceDepth above 2000 is not supported (three launches per level and batch)"); return FRAYHIP_E_UNSUPPORTED; }
+            // Random words a camera sample may draw from one generator: lens samples (DOF, both eyes) and ten per Lambert bounce (main.cpp:219-236,
+            // lights.cpp:62-63).  Up to 227 the generators are three registers; beyond that every path gets two 624-word columns (MtPath).
+            const bool longRng = 8 + 10 * (set.maxTraceDepth + 2) > 227;
+            const size_t perPath = 240 + (longRng ? 2 * 624 * sizeof(uint32_t) : 0);
             // Batches of `chunk` samples per pixel; up to FRAY_PT_LANES batches are in flight at once, each on its own
             // stream with its own queues, so one batch's launch gaps, scans and kernel tails are filled by the others'
             // blocks.  Only the resolves are ordered (evResolved): the per-pixel sum runs in sample order.
             const int maxLanes = std::max(1, std::min(sc->ptLanes, FRAY_PT_LANES));
-            const size_t budget = std::max<size_t>(sc->ptBudgetBytes / 240, 1);       // paths in flight over all lanes (240 B each)
+            const size_t budget = std::max<size_t>(sc->ptBudgetBytes / perPath, 1);       // paths in flight over all lanes
             int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / maxLanes / (size_t)nItems);
             if (chunk > spp) chunk = spp;
             if (f->spp_chunk <= 0 && spp >= 2 * maxLanes && chunk * maxLanes > spp) chunk = (spp + maxLanes - 1) / maxLanes;   // enough batches to fill the lanes
@@ -182,7 +186,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             // per-wave segments round their share up to a multiple of 64: one extra wave-load per wave of the grid
             const size_t nQueue = nPaths + (size_t)grid_for(nPaths) * 4 * 128;
             const bool stereo = sc->camera.stereoSeparation > 0;
-            const size_t laneBytes = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + nPaths * 4 + 4096 +
+            const size_t laneBytes = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + nPaths * 4 + 4096 + (longRng ? nPaths * 2 * 624 * sizeof(uint32_t) + 256 : 0) +
                                      (stereo ? nPaths * (12 + 6 * 8 + 6 * 4) + 16 * 256 : 0);
             int rc = ensure_work(sc, (size_t)nLanes * laneBytes + (size_t)nItems * 12 + 4096);
             if (rc) return rc;
@@ -192,6 +196,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 ShadowQueue SQ;
                 float *sampleRad, *sampleRadR;
                 uint32_t* x397;
+                uint32_t* mtCols;
                 StereoBuf SB;
                 QMeta* meta;
             } lane[FRAY_PT_LANES];
@@ -206,6 +211,8 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 p = carve_shadow(p, nQueue, L.SQ);
                 L.sampleRad = (float*)p; p += (nPaths * 12 + 255) / 256 * 256;
                 L.x397 = (uint32_t*)p; p += (nPaths * 4 + 255) / 256 * 256;
+                L.mtCols = nullptr;
+                if (longRng) { L.mtCols = (uint32_t*)p; p += (nPaths * 2 * 624 * sizeof(uint32_t) + 255) / 256 * 256; }
                 L.SB = StereoBuf{};
                 L.sampleRadR = nullptr;
                 if (stereo) {
@@ -239,8 +246,13 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                         hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
                         if (!ea || !eb || !ec || !ed) return FRAYHIP_E_NOMEM;
                         HIP_TRY(hipEventRecord(ea, ls));
-                        hipLaunchKernelGGL(k_pt_bounce<ST>, dim3(grid), dim3(256), 0, ls, S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ,
-                                           mIn, L.meta + ((b + 1) & 1), L.meta + 2, rad, save, sc->d_stats);
+                        const LongRng LR{L.mtCols, (uint32_t)nPaths, F, nItems, s0};
+                        if (longRng)
+                            hipLaunchKernelGGL((k_pt_bounce<ST, true>), dim3(grid), dim3(256), 0, ls, S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ,
+                                               mIn, L.meta + ((b + 1) & 1), L.meta + 2, rad, save, LR, sc->d_stats);
+                        else
+                            hipLaunchKernelGGL((k_pt_bounce<ST, false>), dim3(grid), dim3(256), 0, ls, S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ,
+                                               mIn, L.meta + ((b + 1) & 1), L.meta + 2, rad, save, LR, sc->d_stats);
                         HIP_TRY(hipEventRecord(eb, ls));
                         nTraceEvents += 2;
                         hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, ls, L.meta + ((b + 1) & 1), L.meta + 2);

@@ -606,3 +606,24 @@ def test_negative_trace_depth_is_a_black_frame(fray, abi, oracle, gpu, gi):
     assert st["samples"] == ost["samples"] == 61 * 47 * s.samples_per_pixel()
     assert st["closest_rays"] == ost["closest_rays"] == 0
     s.close()
+
+
+@pytest.mark.parametrize("depth,stereo", [(40, 0.0), (25, 1.5), (150, 0.0), (400, 0.0)])
+def test_path_tracing_past_227_random_words_per_sample(fray, abi, oracle, gpu, depth, stereo):
+    """maxTraceDepth >= 20: a path may draw more than 227 words from a generator (ten per Lambert bounce), which the three-register
+    mt19937 streams do not cover; the bounce kernel then runs with per-path materialised generator state (MtPath).  The scene keeps
+    throughput: paths reach the depth limit, several hundred words from each generator and, at depth 400, a second state twist."""
+    s = fray.Scene.parseScene(os.path.join(ROOT, "tests", "scenes", "whitebox.fray"))
+    s.settings.maxTraceDepth = depth
+    s.camera.stereoSeparation = stereo
+    s.beginRender()
+    img, st = s.render(seed=42, stats=True)
+    ref, ost = oracle.render(s.desc, abi.MODE_RENDER, seed=42)
+    assert np.all(np.isfinite(img)) and ref.mean() > 0.05
+    assert np.all(rms(img, ref) <= RMS_TOL), rms(img, ref)
+    assert st["samples"] == ost["samples"]
+    # paths really get that deep
+    assert ost["closest_rays"] > 0.8 * min(depth, 300) * ost["samples"]
+    img2, _ = s.render(seed=42)
+    assert np.array_equal(img, img2)
+    s.close()

@@ -26,9 +26,9 @@
 #endif
 
 // Envelope of the device CSG code (dev_trace.hpp csg_intersect); frayhip_scene_create checks scenes against it.
-#define FRAY_CSG_MAX 16   // intersections kept per operand (the reference keeps up to 30)
+#define FRAY_CSG_MAX 30   // intersections kept per operand: the reference's own limit (geometry.cpp:144)
 #ifndef FRAY_CSG_DEPTH
-#define FRAY_CSG_DEPTH 3  // CsgOp levels: 1 = operands are plain geometries, 3 = a CSG of CSGs of CSGs (deeper scenes are rejected at upload)
+#define FRAY_CSG_DEPTH 8  // CsgOp levels the device unrolls: 1 = operands are plain geometries; deeper scenes are rejected at upload
 #endif
 
 struct DXform { double off[3]; double m[9]; double inv[9]; };

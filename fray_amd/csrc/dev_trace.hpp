@@ -11,6 +11,7 @@
 #pragma once
 #include "dev_math.hpp"
 #include "dev_scene.hpp"
+#include "dev_sort.hpp"
 
 // Per-lane work counters (frayhip_stats); only the <true> instantiations touch them.
 struct Cnt {
@@ -341,15 +342,22 @@ FD bool prim_intersect(const DScene& S, int kind, int index, V3 s, V3 d, V3 rd, 
 
 template <int ST, int LEVELS>
 FD bool csg_intersect(const DScene& S, const FRAY_RO DCsg& G, V3 s, V3 d, V3 rd, GHit& win, bool& envelope, Cnt& c);
+// A CsgOp operand that is itself a CsgOp: an out-of-line call per nesting level (inlining the levels into one another
+// would copy the whole geometry code once per level and call site).
+template <int ST, int LEVELS>
+__device__ __attribute__((noinline)) bool csg_child(const DScene& S, int index, V3 s, V3 d, V3 rd, GHit& h, bool& envelope, Cnt& c)
+{
+    return csg_intersect<ST, LEVELS>(S, S.csgs[index], s, d, rd, h, envelope, c);
+}
 
 // operand->intersect(ray, info) of a CsgOp whose own subtree has LEVELS more CsgOp levels available.
 // The reference recurses through the Geometry virtual (geometry.cpp:146); here the recursion is
-// unrolled by the template parameter, one call site per level.
+// unrolled by the template parameter.
 template <int ST, int LEVELS>
 FD bool operand_intersect(const DScene& S, int kind, int index, V3 s, V3 d, V3 rd, GHit& h, bool& envelope, Cnt& c)
 {
     if (kind == 4) {
-        if constexpr (LEVELS > 0) return csg_intersect<ST, LEVELS - 1>(S, S.csgs[index], s, d, rd, h, envelope, c);
+        if constexpr (LEVELS > 0) return csg_child<ST, LEVELS - 1>(S, index, s, d, rd, h, envelope, c);
         envelope = true;          // unreachable: frayhip_scene_create rejects deeper trees
         return false;
     }
@@ -359,39 +367,55 @@ FD bool operand_intersect(const DScene& S, int kind, int index, V3 s, V3 d, V3 r
 }
 
 // CsgOp::intersect (geometry.cpp:139-194).  The winner carries the leaf geometry that produced it.
-// Hits are ordered with a stable insertion sort, which is what libstdc++'s std::sort does for up
-// to 16 elements; beyond that equal-distance ties could be ordered differently, and more than
-// FRAY_CSG_MAX hits on one operand are reported through `envelope`.
+// findAllIntersections keeps up to 30 intersections per operand (geometry.cpp:144-152); per level only their distances
+// are kept, ordered exactly as libstdc++'s std::sort orders them (dev_sort.hpp: the sort is not stable, and coincident
+// faces of two operands are equally distant).  The winning intersection's full record is then derived again by a second
+// pass over that operand's chain up to it -- the same calls on the same rays, so the same bits -- which keeps a level's
+// scratch at 540 bytes.  Both passes share ONE call site of operand_intersect.
 template <int ST, int LEVELS>
 FD bool csg_intersect(const DScene& S, const FRAY_RO DCsg& G, V3 s, V3 d, V3 rd, GHit& win, bool& envelope, Cnt& c)
 {
-    GHit hits[2 * FRAY_CSG_MAX];
-    unsigned char side[2 * FRAY_CSG_MAX];
+    double dist[2 * FRAY_CSG_MAX];
+    unsigned char order[2 * FRAY_CSG_MAX];
     int n = 0, cnt[2] = {0, 0};
-    for (int op = 0; op < 2; op++) {   // findAllIntersections, geometry.cpp:139-159
-        const int kind = op == 0 ? G.leftKind : G.rightKind, index = op == 0 ? G.leftIndex : G.rightIndex;
-        V3 start = s;
-        GHit h;
-        while (operand_intersect<ST, LEVELS>(S, kind, index, start, d, rd, h, envelope, c)) {
-            if (cnt[op] == FRAY_CSG_MAX) { envelope = true; break; }
-            if (cnt[op] > 0) h.dist = length(h.ip - s);
-            hits[n] = h; side[n] = (unsigned char)op; n++; cnt[op]++;
-            start = h.ip + d * 1e-6;
+    int winOp = 0, winK = 0;
+    double winDist = 0;
+    Cnt quiet = c;                                                          // pass 1 repeats work that pass 0 counted
+    for (int pass = 0; pass < 2; pass++) {
+        for (int op = pass == 0 ? 0 : winOp; op < (pass == 0 ? 2 : winOp + 1); op++) {   // findAllIntersections, geometry.cpp:139-159
+            const int kind = op == 0 ? G.leftKind : G.rightKind, index = op == 0 ? G.leftIndex : G.rightIndex;
+            V3 start = s;
+            GHit h;
+            int k = 0;
+            while (operand_intersect<ST, LEVELS>(S, kind, index, start, d, rd, h, envelope, pass == 0 ? c : quiet)) {
+                if (pass == 0) {
+                    if (k == FRAY_CSG_MAX) break;                           // `counter-- > 0`: the 31st intersection is found and dropped
+                    dist[n] = k > 0 ? length(h.ip - s) : h.dist;            // geometry.cpp:155-156
+                    order[n] = (unsigned char)n;
+                    n++;
+                } else if (k == winK) {
+                    win = h;
+                    win.dist = winDist;
+                    return true;
+                }
+                k++;
+                start = h.ip + d * 1e-6;
+            }
+            if (pass == 0) cnt[op] = k;
         }
-    }
-    for (int i = 1; i < n; i++) {      // stable insertion sort by dist
-        GHit h = hits[i];
-        unsigned char sd = side[i];
-        int j = i;
-        while (j > 0 && h.dist < hits[j - 1].dist) { hits[j] = hits[j - 1]; side[j] = side[j - 1]; j--; }
-        hits[j] = h; side[j] = sd;
-    }
-    bool inL = (cnt[0] & 1) == 1, inR = (cnt[1] & 1) == 1;
-    auto bop = [&](bool l, bool r) { return G.op == 0 ? (l || r) : (G.op == 1 ? (l && r) : (l && !r)); };
-    const bool cur = bop(inL, inR);
-    for (int i = 0; i < n; i++) {
-        if (side[i] == 0) inL = !inL; else inR = !inR;
-        if (bop(inL, inR) != cur) { win = hits[i]; return true; }
+        if (pass == 1) return false;                                        // unreachable: pass 0 found this intersection
+        StdSort sorter{dist, order};
+        sorter.sort(n);
+        bool inL = (cnt[0] & 1) == 1, inR = (cnt[1] & 1) == 1;
+        auto bop = [&](bool l, bool r) { return G.op == 0 ? (l || r) : (G.op == 1 ? (l && r) : (l && !r)); };
+        const bool cur = bop(inL, inR);
+        bool any = false;
+        for (int i = 0; i < n && !any; i++) {
+            const int e = order[i], op = e < cnt[0] ? 0 : 1;
+            if (op == 0) inL = !inL; else inR = !inR;
+            if (bop(inL, inR) != cur) { any = true; winOp = op; winK = op == 0 ? e : e - cnt[0]; winDist = dist[e]; }
+        }
+        if (!any) return false;
     }
     return false;
 }

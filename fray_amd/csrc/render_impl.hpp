@@ -294,7 +294,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     }
 #endif
     if (dsv[0].rngOverflow || dsv[1].rngOverflow) {
-        set_error("frayhip_render: a camera sample left the supported envelope (path tracing: more than 227 random words per sample; Whitted: shade() nesting deeper than 40; CSG: more than 16 hits on one operand)");
+        set_error("frayhip_render: a camera sample left the supported envelope (Whitted: shade() nesting deeper than 40, or a camera sample whose pixel jitter stream passed 227 words)");
         return FRAYHIP_E_UNSUPPORTED;
     }
     if (st) {

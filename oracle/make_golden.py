@@ -35,6 +35,7 @@ CASES = [
     ("axe_whitted", "hw9/axe_test.fray", 48, 36, "wantAA=0", 3, 300),
     ("nonconvex_aa", "hw9/nonconvex.fray", 48, 36, "wantAA=1", 3, 200),
     ("csg_nested", "../tests/scenes/csg_nested.fray", 60, 45, "wantAA=0", 2, 400),       # this repository's scene: CsgOp trees three levels deep
+    ("csg_deep", "../tests/scenes/csg_deep.fray", 48, 36, "wantAA=0", 2, 400),           # this repository's scene: six CsgOp levels, an operand with up to 22 intersections (introsort ties)
     ("fuzz1009_pt", "../tests/scenes/fuzz1009/scene.fray", 76, 32, "gi=1;numPaths=4", 2, 400),   # a generated scene that caught a path-tracing mismatch
     # forest with its cubemap LOADED: the reference's CubemapEnvironment::loadMaps / getEnvironment object code (environment.cpp:31-98)
     # on the faces this project's EXR decoder produced (handed to oracle/ref_glue.cpp's Bitmap::loadEXR as plain texel files)

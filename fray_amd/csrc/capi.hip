@@ -672,12 +672,12 @@ __global__ void k_debug_libm(int n, const double* x, double* out)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         double sn, cs;
-        sincos(x[i], &sn, &cs);
+        fray_sincos(x[i], &sn, &cs);
         out[i] = sn;
         out[n + i] = cs;
         double a = x[i];
         a = a - 2.0 * floor(a * 0.5) - 1.0;                 // folded into [-1, 1) for acos
-        out[2 * n + i] = acos(a);
+        out[2 * n + i] = fray_acos(a);
         out[3 * n + i] = a;
     }
 }

@@ -12,6 +12,7 @@
 // call then fails instead of returning numbers that differ from the reference).
 #pragma once
 #include "dev_math.hpp"
+#include "dev_trig.hpp"
 
 struct Mt { uint32_t j, a, b; FD uint32_t next(); };
 
@@ -111,7 +112,7 @@ FD void rng_unit_disc(G& r, double& x, double& y)
     double angle = rng_double(r) * 2 * FRAY_PI;
     double rad = sqrt(rng_double(r));
     double sa, ca;
-    sincos(angle, &sa, &ca);
+    fray_sincos(angle, &sa, &ca);
     x = sa * rad;
     y = ca * rad;
 }

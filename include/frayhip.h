@@ -335,10 +335,10 @@ int  frayhip_save_bmp(const char* path, const float* rgb, int width, int height)
  * generator's 227-word register window and two full state twists). */
 int  frayhip_debug_rng(uint32_t seed, int n, float* floats, double* doubles, int32_t* ints, int int_hi);
 
-/* Test hook: the device's sincos(x[i]) and acos(fold(x[i])) -- the libm calls behind
- * hemisphereSample / unitDiscSample (main.cpp:92-116, random_generator.cpp:71-80), which the
- * reference takes from glibc -- so that a test can state how far the two libms are apart.
- * fold(x) = x - 2*floor(x/2) - 1 in [-1, 1) is returned in acos_arg.  Host buffers of n doubles,
+/* Test hook: the device's sin / cos / acos behind hemisphereSample / unitDiscSample (main.cpp:92-116,
+ * random_generator.cpp:71-80; the reference takes them from glibc, the device code has its own correctly rounded
+ * ones, fray_amd/csrc/dev_trig.hpp) -- sincos(x[i]) and acos(fold(x[i])), so that a test can state how often they
+ * equal the host's.  fold(x) = x - 2*floor(x/2) - 1 in [-1, 1) is returned in acos_arg.  Host buffers of n doubles,
  * any output may be NULL. */
 int  frayhip_debug_libm(int n, const double* x, double* sin_out, double* cos_out, double* acos_out, double* acos_arg);
 

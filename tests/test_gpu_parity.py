@@ -598,9 +598,11 @@ def test_cxx_host_example_renders_like_the_python_path(fray, gpu, tmp_path):
 
 
 def test_device_libm_vs_glibc(fray, gpu):
-    """sin / cos / acos are the reference's third-party arithmetic (glibc); the device has ROCm's.  They must
-    agree to the last place or two -- which is what keeps colour parity at ~1e-8 -- and this states how often
-    they agree exactly on the arguments the samplers produce (theta in [0, 2 pi), 2v-1 in [-1, 1))."""
+    """sin / cos / acos are the reference's third-party arithmetic (glibc).  The device code carries its own, correctly rounded in
+    all but a few calls per million (fray_amd/csrc/dev_trig.hpp, checked against 113-bit arithmetic by tests/native/trig_check.cpp);
+    glibc's are the correctly rounded values in 99.85 % of calls, so the two must be IDENTICAL in more than 99.5 % of calls on the
+    arguments the samplers produce (theta in [0, 2 pi), 2v-1 in [-1, 1)) and never more than one place apart.  (ROCm's own functions
+    matched glibc in 96.9 % / 93.4 % of calls.)"""
     import math
     rng = np.random.default_rng(7)
     n = 1 << 16
@@ -616,12 +618,10 @@ def test_device_libm_vs_glibc(fray, gpu):
     glibc = lambda f, v: np.array([f(t) for t in v.tolist()])
     for name, got, want in (("sin", sn, glibc(math.sin, x)), ("cos", cs, glibc(math.cos, x)), ("acos", ac, glibc(math.acos, arg))):
         u = ulps(got, want)
-        near_zero = np.abs(want) < 1e-3                     # ulps of a tiny result say little; compare absolutely there
-        assert u[~near_zero].max() <= 2, (name, int(u[~near_zero].max()))
-        assert np.abs(got - want)[near_zero].max(initial=0.0) <= 1e-18, name
+        assert u.max() <= 1, (name, int(u.max()))
         exact = float((u == 0).mean())
-        print("%s: identical to glibc in %.2f %% of %d calls, max %d ulp" % (name, 100 * exact, n, int(u[~near_zero].max())))
-        assert exact > 0.5, (name, exact)
+        print("%s: identical to glibc in %.3f %% of %d calls" % (name, 100 * exact, n))
+        assert exact > 0.995, (name, exact)
 
 
 @pytest.mark.parametrize("gi", [0, 1])

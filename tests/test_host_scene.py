@@ -355,3 +355,20 @@ def test_loaders_under_address_and_ub_sanitizers(tmp_path):
     for name in ("window_overflow.exr", "window_overflow_y.exr", "offset_wrap_0.exr", "offset_wrap_1.exr", "offset_wrap_2.exr",
                  "lying_height.bmp", "negative_colours.bmp"):
         assert lines[name] == "rejected", name
+
+
+def test_device_trig_and_sort_restatements_on_the_host(tmp_path):
+    """Two device headers that restate library arithmetic compile for the host too and are checked against the libraries here:
+    dev_trig.hpp (sin / cos / acos) must be correctly rounded -- compared with 113-bit libquadmath -- in all but 2 calls per 10^4 (it
+    is ~5 per 10^6), and dev_sort.hpp must order every input, ties included, exactly as this toolchain's std::sort does."""
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    inc = "-I" + os.path.join(root, "fray_amd", "csrc")
+    exe = str(tmp_path / "trig_check")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", inc, os.path.join(root, "tests", "native", "trig_check.cpp"), "-o", exe, "-lquadmath"], check=True)
+    r = subprocess.run([exe, "1000000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    exe = str(tmp_path / "sort_check")
+    subprocess.run(["g++", "-std=c++17", "-O2", inc, os.path.join(root, "tests", "native", "sort_check.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "heapsort fallbacks exercised" in r.stdout and " 0 heapsort" not in r.stdout, r.stdout

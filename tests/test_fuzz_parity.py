@@ -141,9 +141,10 @@ def test_coincident_opposite_triangles(fray, abi, oracle, gpu, tmp_path):
     no back-face culling.  Both copies are hit at distances that differ in the last bits at most, so which
     one wins -- and with it the sign of the raw normal that Lambert::eval / spawnRay use -- follows the last
     bit of the ray direction.  Camera rays are computed identically on both sides: hit records and the
-    first bounce agree bit for bit.  Directions of later bounces come out of sin / cos / acos, where the
-    device's libm and glibc differ in the last place now and then, so a handful of paths that meet the
-    twin triangles again take the other normal.  The oracle equals the reference's own code on this scene
+    first bounce agree bit for bit.  Directions of later bounces come out of sin / cos / acos.  With ROCm's
+    functions (which differ from glibc in the last place in 3-7 % of calls) 3-4 of the 2432 pixels took the
+    other normal; with the device code's own correctly rounded ones (dev_trig.hpp: glibc's value in 99.85 %
+    of calls) none does on this frame -- two are allowed for the calls where glibc itself rounds the other way.  The oracle equals the reference's own code on this scene
     (tests/golden/ref_fuzz1009_pt.npz); the device must differ in those few pixels only, and not at all once
     the twin is removed or culled."""
     import shutil
@@ -171,7 +172,8 @@ def test_coincident_opposite_triangles(fray, abi, oracle, gpu, tmp_path):
     ids, diff = render()
     bad = (diff > 1e-5).any(axis=2)
     shard = 6                                              # floorNode, n0..n4, then n5 = shard
-    assert bad.sum() <= 12 and np.all(ids[bad] == shard), (int(bad.sum()), np.unique(ids[bad]))
+    print("fuzz1009: %d of %d pixels differ from the oracle" % (int(bad.sum()), bad.size))
+    assert bad.sum() <= 2 and np.all(ids[bad] == shard), (int(bad.sum()), np.unique(ids[bad]))
     assert np.sqrt((diff[~bad] ** 2).mean()) <= 1e-6
     ids, diff = render(maxTraceDepth=0)                    # camera ray + its next-event sample: no libm in the directions
     assert np.sqrt((diff ** 2).mean()) <= 1e-6

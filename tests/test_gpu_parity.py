@@ -508,7 +508,8 @@ def test_gpu_colour_vs_reference_fixture(fray, gpu, path):
         # test_fuzz_parity.py::test_coincident_opposite_triangles); every other pixel must match
         diff = np.abs(img.astype(np.float64) - z["image"])
         bad = (diff > 1e-5).any(axis=2)
-        assert bad.sum() <= 12 and np.sqrt((diff[~bad] ** 2).mean()) <= 1e-6, int(bad.sum())
+        print("ref_fuzz1009_pt: %d of %d pixels differ from the reference fixture" % (int(bad.sum()), bad.size))
+        assert bad.sum() <= 2 and np.sqrt((diff[~bad] ** 2).mean()) <= 1e-6, int(bad.sum())
         s.close()
         return
     assert np.all(rms(img, z["image"]) <= RMS_TOL), rms(img, z["image"])

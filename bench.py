@@ -31,6 +31,8 @@ WORKLOADS = {
     "smallpt_4k_pt1024": ("smallpt.fray", 4096, 4096, dict(gi=1, numPaths=1024),
                           "smallpt.fray 4096x4096 1024spp path trace, maxTraceDepth 8 (BASELINE configs[4] on one GPU; use --steps 1 --warmup 0)"),
     "dragon_primary": ("hw9/dragon.fray", 1920, 1080, dict(wantAA=0), "hw9/dragon.fray 1920x1080 primary rays (100k-triangle KD)"),
+    "forest_primary": ("forest.fray", 1920, 1080, dict(wantAA=0, interactive=0), "forest.fray 1920x1080 primary rays (closest hit only)"),
+    "boxed_primary": ("boxed.fray", 1920, 1080, dict(wantAA=0), "boxed.fray 1920x1080 primary rays (closest hit only)"),
 }
 
 
@@ -327,7 +329,10 @@ def main():
     if rank == 0:
         from tools.source_hash import source_hash
         src = source_hash()
-        kern = {abi.MODE_PRIMARY_ID: "k_primary"}.get(mode, "k_pt_bounce" if scene.settings.gi else "k_whitted")
+        # the kernel whose launches ms_trace / alg_flops_trace describe, and the one behind ms_shadow / alg_flops_shadow
+        wavefront_whitted = mode == abi.MODE_RENDER and not scene.settings.gi and shadow_launches > 0
+        kern = {abi.MODE_PRIMARY_ID: "k_primary"}.get(mode, "k_pt_bounce" if scene.settings.gi else ("k_wh_shade" if wavefront_whitted else "k_whitted"))
+        kern_shadow = "k_pt_shadow" if scene.settings.gi else "k_wh_visible"
         # launch durations: serialised pass for path tracing, the timed region itself otherwise (one kernel, one stream)
         tr_ms = serial["ms_trace"] if serial else trace_ms / args.steps
         tr_n = serial["trace_launches"] if serial else trace_launches / args.steps
@@ -371,13 +376,19 @@ def main():
                                         "note": "timed region; launches of up to four batch lanes overlap, so these sums exceed ms_per_step"},
         }
         out["roofline_hbm"]["frac"] = out["roofline_hbm"]["achieved"] / 8000.0
-        if serial and serial["shadow_launches"]:
-            sms = serial["ms_shadow"] / serial["shadow_launches"]
-            sf = st_counts["alg_flops_shadow"] / serial["shadow_launches"]
-            out["roofline_shadow_kernel"] = {"bound": "fp64_valu", "kernel": "k_pt_shadow", "achieved": sf / (sms * 1e-3) / 1e12, "peak": FP64_PEAK, "unit": "TFLOP/s",
+        sh_ms = serial["ms_shadow"] if serial else shadow_ms / args.steps
+        sh_n = serial["shadow_launches"] if serial else shadow_launches / args.steps
+        if sh_n and sh_ms > 0:
+            sms = sh_ms / sh_n
+            sf = st_counts["alg_flops_shadow"] / sh_n
+            out["roofline_shadow_kernel"] = {"bound": "fp64_valu", "kernel": kern_shadow, "achieved": sf / (sms * 1e-3) / 1e12, "peak": FP64_PEAK, "unit": "TFLOP/s",
                                              "frac": sf / (sms * 1e-3) / 1e12 / FP64_PEAK, "alg_flops_per_launch": sf, "avg_launch_ms": sms,
-                                             "launches_per_step": serial["shadow_launches"], "sum_launch_ms_per_step": serial["ms_shadow"],
-                                             "alg_bytes_per_launch": st_counts["alg_bytes_shadow"] / serial["shadow_launches"]}
+                                             "launches_per_step": sh_n, "sum_launch_ms_per_step": sh_ms,
+                                             "alg_bytes_per_launch": st_counts["alg_bytes_shadow"] / sh_n}
+            if sh_ms > tr_ms:         # the shadow-ray kernel is the dominant one of this workload (e.g. boxed: 32 of 33 rays): it is THE roofline
+                out["roofline"], out["roofline_shade_kernel"] = dict(out["roofline_shadow_kernel"], traffic=None, counters=None, source_hash=src,
+                                                                     durations_from=out["roofline"]["durations_from"]), out["roofline"]
+                del out["roofline_shadow_kernel"]
         if check is not None:
             out["gathered_frame_equals_single_rank_frame"] = check
         if transport:
@@ -390,9 +401,9 @@ def main():
             try:
                 pmc = json.load(open(pmc_path))
                 if pmc.get("source_hash") == src and pmc.get("workload") == args.workload:
-                    for key, kname in (("roofline", kern), ("roofline_shadow_kernel", "k_pt_shadow")):
-                        k = pmc["kernels"].get(kname)
-                        if k and key in out:
+                    for key in ("roofline", "roofline_shadow_kernel", "roofline_shade_kernel"):
+                        k = pmc["kernels"].get(out[key]["kernel"]) if key in out else None
+                        if k:
                             out[key]["traffic"] = k.get("hbm_bytes_per_launch")
                             out[key]["traffic_note"] = k.get("hbm_note")
                             out[key]["counters"] = k.get("derived")

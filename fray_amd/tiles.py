@@ -46,11 +46,11 @@ class LibraryGather:
         if rank == 0:
             buf = (C.c_char * 128)()
             rc = lib.frayhip_comm_unique_id(buf)
-            if rc:
-                raise _scene.FrayError(rc, lib.frayhip_last_error().decode())
-            ident = [bytes(buf)]
+            ident = [bytes(buf)] if rc == 0 else [(rc, lib.frayhip_last_error().decode())]
         if world > 1:
-            dist.broadcast_object_list(ident, src=0)
+            dist.broadcast_object_list(ident, src=0)       # every rank learns rank 0's outcome: nobody is left waiting for an id that never comes
+        if not isinstance(ident[0], bytes):
+            raise _scene.FrayError(*ident[0])
         self._comm = C.c_void_p()
         rc = lib.frayhip_comm_create(ident[0], rank, world, C.byref(self._comm))
         if rc:

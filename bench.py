@@ -94,7 +94,8 @@ def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0, gpu_frame=None):
             mask[by * 48:by * 48 + 48, bx * 48:bx * 48 + 48] = True
         d = gpu_frame[mask].astype(np.float64) - cpu_img[mask]
         parity = {"pixels": int(mask.sum()), "rms_per_channel": [float(v) for v in np.sqrt((d ** 2).mean(axis=0))],
-                  "max_abs": float(np.abs(d).max()), "tolerance": 1e-4}
+                  "max_abs": float(np.abs(d).max()), "tolerance": 1e-4,
+                  "bit_identical_pixels": float((gpu_frame[mask] == cpu_img[mask]).all(axis=1).mean())}
     rays = st["closest_rays"] + st["shadow_rays"]
     n_b = len(range(0, nb, stride))
     # single-thread figure on a smaller sample (~4 s)

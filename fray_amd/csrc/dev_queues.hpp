@@ -34,6 +34,17 @@ struct WhittedQueue {
     unsigned char* vis;                 // [T][N] filled by k_wh_visible
 };
 
+// Radiance terms of the camera samples of a batch.  pathtrace() returns contribLight + (pathtrace of the next bounce)
+// (main.cpp:240-243): a sample's value is term_0 + (term_1 + (... + term_last)), FP32 additions from the INNERMOST
+// outwards.  Bounce b of a path writes its term -- the next-event contribution, or what ended the path -- to
+// t[(b * nPaths + slot) * 3 ...]; n[slot] = number of terms; k_pt_fold adds them up in the reference's order.
+struct TermBuf {
+    float* t;
+    unsigned short* n;
+    uint32_t nPaths;
+    int b;             // the bounce the launch belongs to
+};
+
 #ifndef FRAY_MAXSEG
 #define FRAY_MAXSEG 8192   // = 2048 blocks x 4 waves, the largest grid grid_for() returns
 #endif

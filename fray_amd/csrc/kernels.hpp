@@ -383,8 +383,8 @@ static __global__ __launch_bounds__(256) void k_wh_gather(DScene S, WhittedQueue
 
 // ---- path tracer (main.cpp:171-244) as a wavefront ---------------------------------------------------
 // Path state, structure of arrays (one lane = one path, consecutive lanes = consecutive entries,
-// so every array is read and written fully coalesced).  80 bytes per path; radiance is accumulated in
-// the per-sample buffer (sampleRad[slot]), in bounce order, by k_pt_shadow and at termination.
+// so every array is read and written fully coalesced).  92 bytes per path; radiance goes to the sample's term
+// list (TermBuf, dev_queues.hpp), one term per bounce, folded innermost-first by k_pt_fold.
 template <class G>
 struct PathStateT {
     V3 o, d;
@@ -501,20 +501,24 @@ FD uint32_t seg_map(const FRAY_RO uint32_t* off, uint32_t nSeg, uint32_t chunk, 
 // left path is traced, and the right path CONTINUES both random generators where the left path stopped.
 // So the left pass parks the right eye's ray and, when a left path ends, its generator cursors, per sample
 // slot; the right pass starts from those.  g[0] == nullptr: nothing to save (mono, or the right pass).
+// `own`: the path's last term, written here; without it the term of this bounce is the next-event contribution, which
+// k_pt_shadow (or path_shade, when no segment was queued) writes.
 template <class G>
-FD void path_finish(float* __restrict__ sampleRad, DStats* st, const PathStateT<G>& s, C3 add, const StereoBuf& SB)
+FD void path_finish(const TermBuf& TB, DStats* st, const PathStateT<G>& s, const StereoBuf& SB)
 {
     const Mt &r = cursor(s.rnd), &t = cursor(s.tab);
     if (SB.g[0]) {
         SB.g[0][s.slot] = r.j; SB.g[1][s.slot] = r.a; SB.g[2][s.slot] = r.b;
         SB.g[3][s.slot] = t.j; SB.g[4][s.slot] = t.a; SB.g[5][s.slot] = t.b;
     }
-    if (add.r != 0 || add.g != 0 || add.b != 0) {      // x + 0 == x: nothing to do for black
-        size_t q = (size_t)s.slot * 3;
-        sampleRad[q] += add.r; sampleRad[q + 1] += add.g; sampleRad[q + 2] += add.b;
-    }
+    TB.n[s.slot] = (unsigned short)(TB.b + 1);
     // the three-register streams end after 227 words; paths that may draw more run the MtPath variant of the bounce kernel
     if (sizeof(G) == sizeof(Mt) && (r.j > 227 || t.j > 227)) atomicAdd(&st->rngOverflow, 1ull);
+}
+FD void term_store(const TermBuf& TB, uint32_t slot, C3 v)
+{
+    const size_t q = ((size_t)TB.b * TB.nPaths + slot) * 3;
+    TB.t[q] = v.r; TB.t[q + 1] = v.g; TB.t[q + 2] = v.b;
 }
 
 // Batch = nItems pixels x `chunk` samples starting at sample s0; slot = s * nItems + item.  The first
@@ -522,7 +526,7 @@ FD void path_finish(float* __restrict__ sampleRad, DStats* st, const PathStateT<
 #define FRAY_DEAD 0xffffffffu
 template <int ST>
 static __global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFrame F, int nItems, int s0, int chunk, PathQueue Q,
-                                                 float* __restrict__ sampleRad, const uint32_t* __restrict__ x397, StereoBuf SB, int eye, DStats* st)
+                                                 unsigned short* __restrict__ termCount, const uint32_t* __restrict__ x397, StereoBuf SB, int eye, DStats* st)
 {
     Cnt c = zero_cnt();
     const uint32_t total = (uint32_t)nItems * (uint32_t)chunk;
@@ -561,8 +565,7 @@ static __global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFr
         } else {
             Q.depthFlags[slot] = FRAY_DEAD;
         }
-        size_t q = (size_t)slot * 3;
-        sampleRad[q] = 0; sampleRad[q + 1] = 0; sampleRad[q + 2] = 0;
+        termCount[slot] = 0;
     }
     if (ST & 1) flush_stats(st, c);
 }
@@ -588,14 +591,16 @@ FD WaveShare wave_share(uint32_t n)
 // segment sa -> sb carrying sc), the real spawnRay, the throughput update and the entry test of the next iteration
 // (`cont`: ps is the path to continue).
 template <int ST, bool BARY, class G>
-FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitRec& h, float* __restrict__ sampleRad, DStats* st, const StereoBuf& SB, bool& cont, bool& shadow,
+FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitRec& h, const TermBuf& TB, DStats* st, const StereoBuf& SB, bool& cont, bool& shadow,
                    V3& sa, V3& sb, C3& sc, Cnt& c)
 {
+    C3 own = c3(0, 0, 0);          // this bounce's term, unless a queued next-event segment will provide it
     if (h.node <= -2) {                                       // main.cpp:201-208
-        C3 add = (ps.flags & RF_DIFFUSE) ? c3(0, 0, 0) : light_color(S.lights[-2 - h.node]) * ps.pm;
-        path_finish(sampleRad, st, ps, add, SB);
+        own = (ps.flags & RF_DIFFUSE) ? c3(0, 0, 0) : light_color(S.lights[-2 - h.node]) * ps.pm;
+        path_finish(TB, st, ps, SB);
     } else if (h.node < 0) {                                  // main.cpp:210-215
-        path_finish(sampleRad, st, ps, environment<ST>(S, ps.d, c) * ps.pm, SB);
+        own = environment<ST>(S, ps.d, c) * ps.pm;
+        path_finish(TB, st, ps, SB);
     } else {
         const FRAY_RO DNode& N = S.nodes[h.node];
         const FRAY_RO DShader& sh = S.shaders[N.shader];
@@ -609,18 +614,19 @@ FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitRec& h, float* _
         C3 brdf;
         float pdf;
         spawn_ray(sh, info, win, ps.tab, wout, brdf, pdf);
-        if (pdf == -1.0f) {
-            path_finish(sampleRad, st, ps, c3(1, 0, 0), SB);
-        } else if (pdf == 0.0f) {
-            path_finish(sampleRad, st, ps, c3(0, 0, 0), SB);
+        if (pdf == -1.0f || pdf == 0.0f) {                    // main.cpp:238-239: the sentinels return without the light contribution
+            own = pdf == -1.0f ? c3(1, 0, 0) : c3(0, 0, 0);
+            shadow = false;
+            path_finish(TB, st, ps, SB);
         } else {
             ps.pm = ps.pm * brdf / pdf;
             ps.o = wout.o; ps.d = wout.d; ps.depth = wout.depth; ps.flags = wout.flags;
-            // entry test of the next pathtrace() call (main.cpp:173-176)
-            if (ps.depth > S.maxTraceDepth || intensity(ps.pm) < 0.01) path_finish(sampleRad, st, ps, c3(0, 0, 0), SB);
+            // entry test of the next pathtrace() call (main.cpp:173-176): it returns black, this bounce's term stays the light contribution
+            if (ps.depth > S.maxTraceDepth || intensity(ps.pm) < 0.01) path_finish(TB, st, ps, SB);
             else cont = true;
         }
     }
+    if (!shadow) term_store(TB, ps.slot, own);
 }
 
 // Survivors and next-event segments of one batch of 64 paths go to the wave's own segments of the output queues
@@ -652,7 +658,7 @@ FD void bounce_emit(const PathQueue& Qout, const ShadowQueue& SQ, uint32_t segBe
 struct LongRng { uint32_t* cols; uint32_t nPaths; DFrame F; int nItems, s0; };
 template <int ST, bool LONG>
 static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, PathQueue Qin, PathQueue Qout, ShadowQueue SQ, QMetaRO metaIn,
-                                                                          QMeta* metaOut, QMeta* metaShadow, float* __restrict__ sampleRad, StereoBuf SB, LongRng LR, DStats* st)
+                                                                          QMeta* metaOut, QMeta* metaShadow, TermBuf TB, StereoBuf SB, LongRng LR, DStats* st)
 {
     typedef typename std::conditional<LONG, MtPath, Mt>::type G;
     Cnt c = zero_cnt();
@@ -691,7 +697,7 @@ static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DSc
                 ps.tab.col = LR.cols + (size_t)624 * LR.nPaths + ps.slot;
             }
             STAMP(8);
-            path_shade<ST, false>(S, ps, h, sampleRad, st, SB, cont, shadow, sa, sb, sc, c);
+            path_shade<ST, false>(S, ps, h, TB, st, SB, cont, shadow, sa, sb, sc, c);
             STAMP(10);
         }
         bounce_emit(Qout, SQ, ws.begin, produced, producedS, cont, shadow, ps, sa, sb, sc);
@@ -706,10 +712,10 @@ static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DSc
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
 
-// visible() for every queued next-event segment (main.cpp:64-80, 143-144); the unobstructed ones add their
-// radiance to their sample.  One segment per sample per bounce, so the read-modify-write has no contender.
+// visible() for every queued next-event segment (main.cpp:64-80, 143-144): the sample's term of this bounce is the
+// segment's radiance if it is unobstructed, black otherwise.
 template <int ST>
-static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(DScene S, ShadowQueue SQ, QMetaRO meta, float* __restrict__ sampleRad, DStats* st)
+static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(DScene S, ShadowQueue SQ, QMetaRO meta, TermBuf TB, DStats* st)
 {
     Cnt c = zero_cnt();
     const FRAY_RO uint32_t* off = meta.p->off;
@@ -728,13 +734,8 @@ static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(DSc
         if (live) {
             const V3 a = v3(SQ.ax[i], SQ.ay[i], SQ.az[i]), b = v3(SQ.bx[i], SQ.by[i], SQ.bz[i]);
             STAMP(0);
-            if (visible<ST>(S, a, b, c)) {
-                C3 add = c3(SQ.cr[i], SQ.cg[i], SQ.cb[i]);
-                if (add.r != 0 || add.g != 0 || add.b != 0) {
-                    size_t q = (size_t)SQ.slot[i] * 3;
-                    sampleRad[q] += add.r; sampleRad[q + 1] += add.g; sampleRad[q + 2] += add.b;
-                }
-            }
+            const bool vis = visible<ST>(S, a, b, c);
+            term_store(TB, SQ.slot[i], vis ? c3(SQ.cr[i], SQ.cg[i], SQ.cb[i]) : c3(0, 0, 0));
         }
         STAMP(13);
     }
@@ -743,6 +744,20 @@ static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(DSc
 #endif
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
+}
+
+// A camera sample's radiance from its terms, innermost first (TermBuf): result = term[n-1]; result = term[k] + result for k = n-2 .. 0.
+static __global__ __launch_bounds__(256) void k_pt_fold(TermBuf TB, uint32_t total, float* __restrict__ sampleRad)
+{
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += gridDim.x * blockDim.x) {
+        C3 result = c3(0, 0, 0);
+        for (int k = (int)TB.n[slot] - 1; k >= 0; k--) {
+            const size_t q = ((size_t)k * TB.nPaths + slot) * 3;
+            result = c3(TB.t[q], TB.t[q + 1], TB.t[q + 2]) + result;
+        }
+        const size_t o = (size_t)slot * 3;
+        sampleRad[o] = result.r; sampleRad[o + 1] = result.g; sampleRad[o + 2] = result.b;
+    }
 }
 
 // vfb[y][x] = (sum over samples in order) / spp  (main.cpp:348-360).  `sum` carries the running

@@ -170,7 +170,8 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             // Random words a camera sample may draw from one generator: lens samples (DOF, both eyes) and ten per Lambert bounce (main.cpp:219-236,
             // lights.cpp:62-63).  Up to 227 the generators are three registers; beyond that every path gets two 624-word columns (MtPath).
             const bool longRng = 8 + 10 * (set.maxTraceDepth + 2) > 227;
-            const size_t perPath = 240 + (longRng ? 2 * 624 * sizeof(uint32_t) : 0);
+            const size_t termBytes = (size_t)(set.maxTraceDepth + 2) * 12 + 2;       // one FP32 RGB term per bounce and sample, and their count
+            const size_t perPath = 240 + termBytes + (longRng ? 2 * 624 * sizeof(uint32_t) : 0);
             // Batches of `chunk` samples per pixel; up to FRAY_PT_LANES batches are in flight at once, each on its own
             // stream with its own queues, so one batch's launch gaps, scans and kernel tails are filled by the others'
             // blocks.  Only the resolves are ordered (evResolved): the per-pixel sum runs in sample order.
@@ -186,7 +187,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             // per-wave segments round their share up to a multiple of 64: one extra wave-load per wave of the grid
             const size_t nQueue = nPaths + (size_t)grid_for(nPaths) * 4 * 128;
             const bool stereo = sc->camera.stereoSeparation > 0;
-            const size_t laneBytes = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + nPaths * 4 + 4096 + (longRng ? nPaths * 2 * 624 * sizeof(uint32_t) + 256 : 0) +
+            const size_t laneBytes = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + nPaths * 4 + 4096 + nPaths * termBytes + 512 + (longRng ? nPaths * 2 * 624 * sizeof(uint32_t) + 256 : 0) +
                                      (stereo ? nPaths * (12 + 6 * 8 + 6 * 4) + 16 * 256 : 0);
             int rc = ensure_work(sc, (size_t)nLanes * laneBytes + (size_t)nItems * 12 + 4096);
             if (rc) return rc;
@@ -197,6 +198,8 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 float *sampleRad, *sampleRadR;
                 uint32_t* x397;
                 uint32_t* mtCols;
+                float* terms;
+                unsigned short* termCount;
                 StereoBuf SB;
                 QMeta* meta;
             } lane[FRAY_PT_LANES];
@@ -211,6 +214,8 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 p = carve_shadow(p, nQueue, L.SQ);
                 L.sampleRad = (float*)p; p += (nPaths * 12 + 255) / 256 * 256;
                 L.x397 = (uint32_t*)p; p += (nPaths * 4 + 255) / 256 * 256;
+                L.terms = (float*)p; p += (nPaths * (size_t)(set.maxTraceDepth + 2) * 12 + 255) / 256 * 256;
+                L.termCount = (unsigned short*)p; p += (nPaths * 2 + 255) / 256 * 256;
                 L.mtCols = nullptr;
                 if (longRng) { L.mtCols = (uint32_t*)p; p += (nPaths * 2 * 624 * sizeof(uint32_t) + 255) / 256 * 256; }
                 L.SB = StereoBuf{};
@@ -238,7 +243,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     // left pass of a stereo frame saves generator cursors at path end; mono and the right pass do not
                     const StereoBuf& save = (stereo && eye == 0) ? L.SB : SBnone;
                     hipLaunchKernelGGL(k_pt_init<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, ls, S, C, F, nItems, s0, cn, L.Q[0],
-                                       rad, L.x397, L.SB, eye, sc->d_stats);
+                                       L.termCount, L.x397, L.SB, eye, sc->d_stats);
                     for (int b = 0; b < nBounce; b++) {
                         const QMetaRO mIn{(const FRAY_RO QMeta*)(L.meta + (b & 1))}, mSh{(const FRAY_RO QMeta*)(L.meta + 2)};
                         const int grid = bounce_grid((size_t)nItems * cn);
@@ -247,20 +252,24 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                         if (!ea || !eb || !ec || !ed) return FRAYHIP_E_NOMEM;
                         HIP_TRY(hipEventRecord(ea, ls));
                         const LongRng LR{L.mtCols, (uint32_t)nPaths, F, nItems, s0};
+                        const TermBuf TB{L.terms, L.termCount, (uint32_t)nPaths, b};
                         if (longRng)
                             hipLaunchKernelGGL((k_pt_bounce<ST, true>), dim3(grid), dim3(256), 0, ls, S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ,
-                                               mIn, L.meta + ((b + 1) & 1), L.meta + 2, rad, save, LR, sc->d_stats);
+                                               mIn, L.meta + ((b + 1) & 1), L.meta + 2, TB, save, LR, sc->d_stats);
                         else
                             hipLaunchKernelGGL((k_pt_bounce<ST, false>), dim3(grid), dim3(256), 0, ls, S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ,
-                                               mIn, L.meta + ((b + 1) & 1), L.meta + 2, rad, save, LR, sc->d_stats);
+                                               mIn, L.meta + ((b + 1) & 1), L.meta + 2, TB, save, LR, sc->d_stats);
                         HIP_TRY(hipEventRecord(eb, ls));
                         nTraceEvents += 2;
                         hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, ls, L.meta + ((b + 1) & 1), L.meta + 2);
                         HIP_TRY(hipEventRecord(ec, ls));
-                        hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid), dim3(256), 0, ls, S, L.SQ, mSh, rad, sc->d_stats + 1);
+                        hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid), dim3(256), 0, ls, S, L.SQ, mSh, TB, sc->d_stats + 1);
                         HIP_TRY(hipEventRecord(ed, ls));
                         nShadowEvents += 2;
                     }
+                    // the samples' terms -> their radiance, in the reference's innermost-first order
+                    hipLaunchKernelGGL(k_pt_fold, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, ls, TermBuf{L.terms, L.termCount, (uint32_t)nPaths, 0},
+                                       (uint32_t)((size_t)nItems * cn), rad);
                 }
                 // the running per-pixel sum takes the batches in sample order
                 if (batch > 0 && nLanes > 1) HIP_TRY(hipStreamWaitEvent(ls, sc->evResolved[(batch - 1) % nLanes], 0));

@@ -34,7 +34,7 @@ inline int hip_error_code(hipError_t e)
     } while (0)
 
 #ifndef FRAY_PT_BUDGET_MIB
-#define FRAY_PT_BUDGET_MIB 16384   // default workspace budget of a path-traced / wavefront-Whitted frame (frayhip_scene_set_option "pt_budget_mib"); headline frame: 4 GiB 140.4 ms, 8 GiB 134.9, 16 GiB 132.5, 32 GiB 132.6, 64 GiB 132.8
+#define FRAY_PT_BUDGET_MIB 24576   // default workspace budget of a path-traced / wavefront-Whitted frame (frayhip_scene_set_option "pt_budget_mib"): the headline frame then runs 8 batches of 8 spp on 4 lanes (338 B per path in flight)
 #endif
 #ifndef FRAY_PT_LANES
 #define FRAY_PT_LANES 4   // headline frame / smallpt 64 spp, ms: 1 lane 150.0 / 136.3, 2 -> 136.9 / 126.5, 3 -> 135.8 / 125.1, 4 -> 135.8 / 123.8, 6 -> 135.2 / 123.9

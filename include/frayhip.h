@@ -270,8 +270,8 @@ int  frayhip_scene_set_view(frayhip_scene* s, const frayhip_camera* camera, cons
 /* Tunables of an uploaded scene (value ranges checked, FRAYHIP_E_ARG otherwise):
  *   "pt_lanes"      1..4   path-tracing batches in flight at once, each on its own HIP stream (default 4;
  *                          1 serialises every launch, which is what a per-kernel profile wants)
- *   "pt_budget_mib" MiB of device memory a path-traced frame may use for its queues (240 B per path in
- *                          flight; default 16384): a frame is cut into batches of samples that fit
+ *   "pt_budget_mib" MiB of device memory a path-traced frame may use for its queues (about 340 B per path in
+ *                          flight; default 24576): a frame is cut into batches of samples that fit
  * The environment variables FRAYHIP_PT_LANES / FRAYHIP_PT_BUDGET_MIB preset them at frayhip_scene_create. */
 int  frayhip_scene_set_option(frayhip_scene* s, const char* name, int64_t value);
 

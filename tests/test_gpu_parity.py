@@ -115,10 +115,17 @@ def test_path_traced_colour_vs_oracle(fray, abi, oracle, gpu, scene, W, H, over)
     else:
         assert ref.max() == 0 and img.max() == 0
     assert np.all(rms(img, ref) <= RMS_TOL), rms(img, ref)
+    # Beyond the tolerance: with the samplers' correctly rounded sin / cos / acos (glibc's values in 99.85 % of calls) and the radiance
+    # terms added innermost-first like the reference's recursion, a path-traced frame equals the oracle's BIT FOR BIT except where a
+    # last-place difference of a direction flips a branch
+    same = float((img == ref).all(axis=2).mean())
+    print("%s %s: %.2f %% of the pixels bit-identical to the oracle" % (scene, over, 100 * same))
+    assert same >= 0.995, same
     eyes = 2 if s.camera.stereoSeparation > 0 else 1
     assert st["samples"] == ost["samples"] == W * H * s.samples_per_pixel() * eyes
     # libm differs in the last ulp between glibc and ocml, so secondary rays may differ in the last
     # bits and a few of them take another branch: ray counts agree to 1e-4, not exactly
+    print("   work counters GPU - oracle:", {k: int(st[k]) - int(ost[k]) for k in COUNTERS})
     for k in ("closest_rays", "shadow_rays", "node_tests"):
         assert abs(st[k] - ost[k]) <= 1e-4 * ost[k] + 2, k
     s.close()

@@ -37,7 +37,7 @@ struct WhittedQueue {
 // Radiance terms of the camera samples of a batch.  pathtrace() returns contribLight + (pathtrace of the next bounce)
 // (main.cpp:240-243): a sample's value is term_0 + (term_1 + (... + term_last)), FP32 additions from the INNERMOST
 // outwards.  Bounce b of a path writes its term -- the next-event contribution, or what ended the path -- to
-// t[(b * nPaths + slot) * 3 ...]; n[slot] = number of terms; k_pt_fold adds them up in the reference's order.
+// t[(b * 3 + channel) * nPaths + slot]; n[slot] = number of terms; k_pt_fold adds them up in the reference's order.
 struct TermBuf {
     float* t;
     unsigned short* n;

@@ -274,9 +274,8 @@ FD V3 hemisphere_sample(G& tab, V3 norm)   // main.cpp:92-116
     double u = rng_double(tab);
     double v = rng_double(tab);
     double theta = 2 * FRAY_PI * u;
-    double phi = fray_acos(2 * v - 1);      // dev_trig.hpp: correctly rounded, which is what glibc's are in 99.85 % of calls
-    double sp, cp, st, ct;
-    fray_sincos(phi, &sp, &cp);
+    double sp, cp, st, ct;          // phi = acos(2 v - 1); dev_trig.hpp: correctly rounded, which is what glibc's are in 99.85 % of calls
+    fray_acos_sincos(2 * v - 1, &sp, &cp);
     fray_sincos(theta, &st, &ct);
     V3 dir = v3(sp * ct, cp, sp * st);
     if (dot(dir, norm) > 0) return dir;

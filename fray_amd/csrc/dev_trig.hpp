@@ -94,3 +94,17 @@ FRAY_TRIG_FN double fray_acos(double v)
     const double d = ((cs.h - v) + cs.l) / sn.h;
     return y0 + d;
 }
+
+// sin and cos of acos(v) -- what fray_sincos(fray_acos(v), ...) returns, without evaluating the table twice: the sine and
+// cosine of the Newton step's starting point are carried over the step (a last place at most) to first order.
+FRAY_TRIG_FN void fray_acos_sincos(double v, double* s, double* c)
+{
+    const double y0 = FRAY_TRIG_LIBM_ACOS(v);
+    if (!(y0 > 0x1p-20 && y0 < 3.1415916)) { fray_sincos(y0, s, c); return; }
+    DD sn, cs;
+    fray_sincos_dd(y0, sn, cs);
+    const double y = y0 + ((cs.h - v) + cs.l) / sn.h;         // = fray_acos(v)
+    const double dy = y - y0;                                  // exact: zero or a unit in the last place
+    *s = sn.h + (sn.l + cs.h * dy);                            // sin(y0 + dy) = sin y0 + cos y0 dy  (dy^2 ~ 2^-104)
+    *c = cs.h + (cs.l - sn.h * dy);
+}

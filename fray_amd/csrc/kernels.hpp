@@ -517,8 +517,8 @@ FD void path_finish(const TermBuf& TB, DStats* st, const PathStateT<G>& s, const
 }
 FD void term_store(const TermBuf& TB, uint32_t slot, C3 v)
 {
-    const size_t q = ((size_t)TB.b * TB.nPaths + slot) * 3;
-    TB.t[q] = v.r; TB.t[q + 1] = v.g; TB.t[q + 2] = v.b;
+    const size_t q = (size_t)TB.b * 3 * TB.nPaths + slot;          // planar: consecutive slots are consecutive words
+    TB.t[q] = v.r; TB.t[q + TB.nPaths] = v.g; TB.t[q + 2 * (size_t)TB.nPaths] = v.b;
 }
 
 // Batch = nItems pixels x `chunk` samples starting at sample s0; slot = s * nItems + item.  The first
@@ -752,8 +752,8 @@ static __global__ __launch_bounds__(256) void k_pt_fold(TermBuf TB, uint32_t tot
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += gridDim.x * blockDim.x) {
         C3 result = c3(0, 0, 0);
         for (int k = (int)TB.n[slot] - 1; k >= 0; k--) {
-            const size_t q = ((size_t)k * TB.nPaths + slot) * 3;
-            result = c3(TB.t[q], TB.t[q + 1], TB.t[q + 2]) + result;
+            const size_t q = (size_t)k * 3 * TB.nPaths + slot;
+            result = c3(TB.t[q], TB.t[q + TB.nPaths], TB.t[q + 2 * (size_t)TB.nPaths]) + result;
         }
         const size_t o = (size_t)slot * 3;
         sampleRad[o] = result.r; sampleRad[o + 1] = result.g; sampleRad[o + 2] = result.b;

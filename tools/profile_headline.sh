@@ -10,7 +10,7 @@ TAG=${1:-r02}
 WL=${2:-cornell_pt64}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT && mkdir -p $OUT      # a re-run must not mix with an older run's files
 export FRAYHIP_PT_LANES=1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload $WL > $OUT/trace_bench.json 2> $OUT/trace.log || echo "trace pass failed"

@@ -84,6 +84,9 @@ def test_whitted_colour_vs_oracle(fray, abi, oracle, gpu, scene, W, H, over):
     ref, ost = oracle.render(s.desc, abi.MODE_RENDER, seed=42)
     assert np.all(np.isfinite(img)) and ref.mean() > 1e-3
     assert np.all(rms(img, ref) <= RMS_TOL), rms(img, ref)
+    same = float((img == ref).all(axis=2).mean())      # beyond the tolerance: the reference's evaluation order + correctly rounded trig
+    print("%s %s: %.2f %% of the pixels bit-identical to the oracle" % (scene, over, 100 * same))
+    assert same >= 0.995, same
     img2, st = s.render(seed=42, stats=True)
     assert np.array_equal(img, img2)                   # instrumented kernels: same image
     for k in COUNTERS:
@@ -520,6 +523,10 @@ def test_gpu_colour_vs_reference_fixture(fray, gpu, path):
         s.close()
         return
     assert np.all(rms(img, z["image"]) <= RMS_TOL), rms(img, z["image"])
+    # and beyond: the fixture is the output of the reference's own shader / light / camera / geometry object code
+    same = float((img == z["image"]).all(axis=2).mean())
+    print("%s: %.2f %% of the pixels bit-identical to the reference fixture" % (os.path.basename(path), 100 * same))
+    assert same >= 0.995, same
     s.close()
 
 

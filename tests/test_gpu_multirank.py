@@ -58,3 +58,30 @@ def test_library_gather_single_rank_and_argument_checks(fray, gpu):
     bad = C.c_void_p()
     assert lib.frayhip_comm_create(None, 0, 2, C.byref(bad)) != 0                              # a world of two needs the id
     assert lib.frayhip_comm_create(bytes(ident), 2, 2, C.byref(bad)) != 0                      # rank outside the world
+
+
+def test_bench_line_contract_single_gpu(tmp_path):
+    """`python bench.py` (N = 1, a short run) prints ONE JSON line with the fields the driver reads, the roofline of the dominant
+    kernel with non-overlapped launch durations, and the CPU baseline with its in-run parity check."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"]
+    out = run_in_clean_child(cmd, str(tmp_path / "bench.log"), timeout=600)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-3000:]
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1 and r["unit"] == "Mrays/s" and r["dtype"] == "f64" and r["vs_baseline"] is None
+    assert "cornell_box.fray 1920x1080 64spp" in r["config"]["workload"]
+    assert abs(r["value"] - r["config"]["rays_per_frame"] / (r["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * r["value"]
+    rf = r["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step"):
+        assert k in rf, k
+    assert rf["kernel"] == "k_pt_bounce" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    # launch durations come from the serialised pass: they add up to less than that pass's frame time
+    assert rf["launches_per_step"] * rf["avg_launch_ms"] <= float(rf["durations_from"].split(",")[1].split()[0])
+    cb = r["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    par = cb["gpu_frame_vs_oracle_on_the_sample"]
+    assert max(par["rms_per_channel"]) <= 1e-4 and par["bit_identical_pixels"] >= 0.99

@@ -8,6 +8,19 @@
 #define FD __device__ __forceinline__
 #include "dev_scene.hpp"
 
+// Truth values of the hottest predicated code as wave-wide lane masks in scalar registers (dev_trace.hpp box_dim).
+// lanes(cmp): one v_cmp writing the mask; only active lanes ever have their bit set.  lane_of(mask): this lane's bit as a
+// bool again (no instruction: the mask is used as the condition).
+#ifdef __HIP_DEVICE_COMPILE__
+typedef unsigned long long lanes_t;
+FD lanes_t lanes(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+FD bool lane_of(lanes_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+#else
+typedef unsigned long long lanes_t;      // host pass: declarations only, never called
+__device__ lanes_t lanes(bool p);
+__device__ bool lane_of(lanes_t m);
+#endif
+
 // Diagnostic build only (-DFRAY_STAMPS, never shipped): s_memtime stamps that attribute a wave's cycles to
 // sections of the trace kernels.  STAMP(k) charges the cycles since the wave's previous stamp to section k.  The
 // sums live in LDS (every active lane writes the same value, so any exec mask works) and leave the kernel

@@ -106,30 +106,35 @@ FD bool tri_test(const FRAY_RO DTri* T, int culling, V3 s, V3 d, double& best, d
     // the whole 120-byte record is fetched up front: one memory round trip per triangle instead
     // of one per early-out stage (the walk is latency-bound, not bandwidth-bound)
     const V3 g = ld3(T->g), N = ld3(T->N), A = ld3(T->A), AC = ld3(T->AC), AB = ld3(T->AB);
-    // straight-line predicated form (see box_dim): every value is the reference's, the early
-    // returns are folded into `ok`
-    bool ok = !(culling && dot(d, g) > 0);
+    // straight-line predicated form (see box_dim): every value is the reference's, the early returns are folded into `ok`.
+    // `ok` is kept as a 64-bit LANE MASK in scalar registers (lanes(): one v_cmp per comparison, combined with s_and), so
+    // "does any lane still need the next stage" is a scalar compare with zero and the lane's own answer is read back for
+    // free (lane_of); written on a bool, every such vote goes through a 0/1 vector register and a vector compare.  A mask
+    // only ever has bits of active lanes.  (The box test stays on bools: the same rewrite measured 2 % slower there.)
+    lanes_t ok = lanes(!(dot(d, g) > 0));
+    if (!culling) ok = lanes(true);
     V3 D = -d;
     double Dcr = dot(N, D);
-    ok &= !(fabs(Dcr) < 1e-12);
-    if (!__any(ok)) return false;           // wave-uniform: every lane culled this triangle
+    ok &= lanes(!(fabs(Dcr) < 1e-12));
+    if (!ok) return false;                  // wave-uniform: every lane culled this triangle
     double rDcr = 1 / Dcr;
     V3 H = s - A;
     double gamma = dot(N, H) * rDcr;
-    ok &= !(gamma < 0 || gamma > best);
-    if (!__any(ok)) return false;           // wave-uniform: nobody needs the barycentrics
+    ok &= lanes(!(gamma < 0)) & lanes(!(gamma > best));
+    if (!ok) return false;                  // wave-uniform: nobody needs the barycentrics
     double l2 = dot(cross(H, AC), D) * rDcr;
-    ok &= !(l2 < 0 || l2 > 1);
+    ok &= lanes(!(l2 < 0)) & lanes(!(l2 > 1));
     double l3 = dot(cross(AB, H), D) * rDcr;
-    ok &= !(l3 < 0 || l3 > 1);
+    ok &= lanes(!(l3 < 0)) & lanes(!(l3 > 1));
     double l1 = 1 - (l2 + l3);
-    ok &= !(l1 < 0);
-    if (ok) {
+    ok &= lanes(!(l1 < 0));
+    const bool hit = lane_of(ok);
+    if (hit) {
         best = gamma;
         l2o = l2;
         l3o = l3;
     }
-    return ok;
+    return hit;
 }
 
 // Mesh::intersectTriangle's barycentrics for a triangle already known to be the winner (the hit queue carries

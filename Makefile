@@ -8,7 +8,10 @@ ARCH    ?= gfx950
 INC     := -Iinclude -Ifray_amd/csrc
 # -ffp-contract=off: the reference build has no FMA contraction (x86-64 baseline); bit-exact hit
 # records need the same on the device.
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt $(INC)
+# -mllvm -disable-machine-licm: MachineLICM hoists the FP64 constants of the inlined polynomials (acos, sin / cos, atan2) out of the
+# kernels' outer loops as VGPR pairs; the register allocator then spills them and every Horner step reloads one from scratch and waits
+# for it.  Without the pass k_pt_bounce needs 146 VGPRs and no scratch (168 + 68 spilled with it): headline frame 135.8 -> 126.9 ms.
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -mllvm -disable-machine-licm $(INC)
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off $(INC)
 
 HOST_SRC := fray_amd/csrc/host_scene.cpp fray_amd/csrc/host_loaders.cpp fray_amd/csrc/host_exr.cpp fray_amd/csrc/capi_host.cpp

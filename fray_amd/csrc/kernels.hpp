@@ -24,8 +24,11 @@
 #ifndef FRAY_WHITTED_WAVES
 #define FRAY_WHITTED_WAVES 3   // measured with persistent waves (boxed / forest DOF16 / zaphod ms): 2 -> 16.7 / 28.9 / 0.34, 3 -> 15.2 / 26.1 / 0.35, 4 -> 15.0 / 26.3 / 0.42, 5 -> 15.4 / 26.2 / 0.53
 #endif
+#ifndef FRAY_WH_SHADE_WAVES
+#define FRAY_WH_SHADE_WAVES 4   // the wavefront's closest-hit + shading kernel: 128 VGPRs, 50 spilled; forest DOF 16 24.1 -> 20.5 ms against 3 waves (168 VGPRs, 2 spilled)
+#endif
 #ifndef FRAY_SHADOW_WAVES
-#define FRAY_SHADOW_WAVES 4
+#define FRAY_SHADOW_WAVES 5     // the any-hit kernels at 96 VGPRs (13 / 8 spilled): boxed Whitted 12.0 -> 11.3 ms, headline -1 % against 4 waves
 #endif
 #ifndef FRAY_BOUNCE_WAVES
 #define FRAY_BOUNCE_WAVES 3   // waves per SIMD the bounce kernel is register-allocated for
@@ -297,7 +300,7 @@ FD void wh_shade_eye(const DScene& S, V3 o, V3 d, MtLong& tab, const WhittedQueu
 }
 
 template <int ST>
-static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_wh_shade(DScene S, DCamera C, DFrame F, int nItems, int s0, int chunk, WhittedQueue Q, uint32_t* mtWork,
+static __global__ __launch_bounds__(256, FRAY_WH_SHADE_WAVES) void k_wh_shade(DScene S, DCamera C, DFrame F, int nItems, int s0, int chunk, WhittedQueue Q, uint32_t* mtWork,
                                                                          const uint32_t* __restrict__ x397, DStats* st)
 {
     Cnt c = zero_cnt();

@@ -9,8 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def source_hash():
     h = hashlib.sha1()
-    files = sorted(glob.glob(os.path.join(ROOT, "fray_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "fray_amd", "csrc", "*.cpp")) +
-                   [os.path.join(ROOT, "include", "frayhip.h"), os.path.join(ROOT, "Makefile")])
+    # exact suffixes only: an editor's or a compiler's leftover next to the sources (x.hpp~, y.hip.tmp) must not change the identity
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "fray_amd", "csrc", "*")) if f.endswith((".hip", ".hpp", ".h", ".cpp")))
+    files += [os.path.join(ROOT, "include", "frayhip.h"), os.path.join(ROOT, "Makefile")]
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())

@@ -7,7 +7,7 @@ python tools/source_hash.py > $OUT/source_hash.txt
 # 1. headline, default mode, with the CPU baseline leg
 timeout -k 10 600 python bench.py --steps 20 --warmup 2 > $OUT/bench_headline.json 2> $OUT/bench_headline.err; echo "headline done" >> $OUT/progress.log
 # 2. the other workloads (one GPU)
-for w in smallpt_pt64 boxed_whitted forest_dof16 forest_dof256 zaphod_whitted dragon_primary; do
+for w in smallpt_pt64 boxed_whitted forest_dof16 forest_dof256 zaphod_whitted dragon_primary smallpt_whitted dragon_whitted; do
   timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err; echo "$w done" >> $OUT/progress.log
 done
 timeout -k 10 300 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --workload smallpt_4k_pt1024 > $OUT/bench_smallpt_4k_pt1024.json 2> $OUT/bench_smallpt_4k_pt1024.err; echo "4k done" >> $OUT/progress.log

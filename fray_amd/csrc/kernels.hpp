@@ -34,6 +34,20 @@
 #define FRAY_BOUNCE_WAVES 3   // waves per SIMD the bounce kernel is register-allocated for
 #endif
 
+// ---- kernel arguments, read where they are used ------------------------------------------------------------
+// A kernel's by-value arguments are all loaded at its entry and kept alive; in the big kernels most of them (scene tables, queue
+// arrays: ~150 scalar registers) end up spilled to VGPR lanes and cost a v_readlane -- a vector-ALU slot -- at every use.  These kernels
+// therefore take ONE struct and read its fields through the kernarg segment (scalar loads, served by the scalar cache) inside the loop:
+// kernel_args() returns the segment's address as a value the compiler cannot see through, once per iteration, so that nothing read
+// through it is hoisted back out of the loop.  k_pt_bounce: 147 -> 13 spilled SGPRs, headline frame 125.4 -> 122.6 ms.
+template <class A> FD const FRAY_RO A* kernel_args()
+{
+    const FRAY_RO A* p = (const FRAY_RO A*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#define KARG(A, P, f) (*(const decltype(A::f)*)(&(P)->f))
+
 // ---- work item -> pixel ------------------------------------------------------------------------
 // Inside a 48x48 bucket the items run over 8x8 pixel tiles (6x6 of them), so the 64 lanes of a wave
 // hold a square of neighbouring pixels: their camera rays walk the same part of a KD-tree.  Every
@@ -158,12 +172,18 @@ static __global__ __launch_bounds__(256) void k_seed(DFrame F, int nItems, int s
 }
 
 // ---- MODE_PRIMARY_ID ------------------------------------------------------------------------------
+struct PrimaryArgs { DScene S; DCamera C; DFrame F; int nItems; int32_t* hitId; double* hitDist; DStats* st; DCursors* cur; };
 template <int ST>
-static __global__ __launch_bounds__(256, FRAY_PRIMARY_WAVES) void k_primary(DScene S, DCamera C, DFrame F, int nItems, int32_t* __restrict__ hitId,
-                                                 double* __restrict__ hitDist, DStats* st, DCursors* cur)
+static __global__ __launch_bounds__(256, FRAY_PRIMARY_WAVES) void k_primary(PrimaryArgs A)
 {
     Cnt c = zero_cnt();
+    const int nItems = A.nItems;
+    DCursors* const cur = A.cur;
     for (int r = 0, item = claim_items(cur, nItems, r); item < nItems; item = claim_items(cur, nItems, r)) {
+        const FRAY_RO PrimaryArgs* AP = kernel_args<PrimaryArgs>();
+        const DScene& S = KARG(PrimaryArgs, AP, S);
+        const DCamera& C = KARG(PrimaryArgs, AP, C);
+        const DFrame& F = KARG(PrimaryArgs, AP, F);
         int x, y;
         if (!item_pixel(F, item, x, y)) continue;
         V3 o, d;
@@ -171,26 +191,37 @@ static __global__ __launch_bounds__(256, FRAY_PRIMARY_WAVES) void k_primary(DSce
         HitRec h;
         closest_hit<ST>(S, o, d, h, c);
         size_t p = (size_t)y * F.W + x;
+        int32_t* const hitId = KARG(PrimaryArgs, AP, hitId);
+        double* const hitDist = KARG(PrimaryArgs, AP, hitDist);
         if (hitId) hitId[p] = h.node;
         if (hitDist) hitDist[p] = h.dist;
     }
-    if (ST & 1) flush_stats(st, c);
-    if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
+    if (ST & 1) flush_stats(A.st, c);
+    if ((ST & 2) && c.envelope) atomicAdd(&A.st->rngOverflow, 1ull);
 }
 
 static __constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0, 0.6}, {0.6, 0.6}};   // main.cpp:55-61
 
 // Whitted, scenes with recursive shaders (Reflection / Refraction / Layered): raytrace() per pixel, samples in order, one lane walks
 // the whole shade() tree (dev_whitted.hpp).  Scenes without them take the wavefront path below (k_wh_shade ...).
+struct WhittedArgs { DScene S; DCamera C; DFrame F; int nItems; float* rgb; uint32_t* mtWork; const uint32_t* x397; DStats* st; DCursors* cur; };
 template <int ST>
-static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(DScene S, DCamera C, DFrame F, int nItems, float* __restrict__ rgb, uint32_t* mtWork,
-                                                 const uint32_t* __restrict__ x397, DStats* st, DCursors* cur)
+static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(WhittedArgs A)
 {
     Cnt c = zero_cnt();
     MtLong tab;
     tab.stride = gridDim.x * blockDim.x;
-    tab.st = mtWork + (blockIdx.x * blockDim.x + threadIdx.x);
+    tab.st = A.mtWork + (blockIdx.x * blockDim.x + threadIdx.x);
+    const int nItems = A.nItems;
+    DCursors* const cur = A.cur;
+    DStats* const st = A.st;
     for (int r = 0, item = claim_items(cur, nItems, r); item < nItems; item = claim_items(cur, nItems, r)) {
+        const FRAY_RO WhittedArgs* AP = kernel_args<WhittedArgs>();
+        const DScene& S = KARG(WhittedArgs, AP, S);
+        const DCamera& C = KARG(WhittedArgs, AP, C);
+        const DFrame& F = KARG(WhittedArgs, AP, F);
+        float* const rgb = KARG(WhittedArgs, AP, rgb);
+        const uint32_t* const x397 = KARG(WhittedArgs, AP, x397);
         int x, y;
         if (!item_pixel(F, item, x, y)) continue;
         const uint32_t p = (uint32_t)y * (uint32_t)F.W + (uint32_t)x;
@@ -299,19 +330,27 @@ FD void wh_shade_eye(const DScene& S, V3 o, V3 d, MtLong& tab, const WhittedQueu
     Q.hit[e] = hit;
 }
 
+struct WhShadeArgs { DScene S; DCamera C; DFrame F; int nItems, s0, chunk; WhittedQueue Q; uint32_t* mtWork; const uint32_t* x397; DStats* st; };
 template <int ST>
-static __global__ __launch_bounds__(256, FRAY_WH_SHADE_WAVES) void k_wh_shade(DScene S, DCamera C, DFrame F, int nItems, int s0, int chunk, WhittedQueue Q, uint32_t* mtWork,
-                                                                         const uint32_t* __restrict__ x397, DStats* st)
+static __global__ __launch_bounds__(256, FRAY_WH_SHADE_WAVES) void k_wh_shade(WhShadeArgs A)
 {
     Cnt c = zero_cnt();
     MtLong tab;
     tab.stride = gridDim.x * blockDim.x;
-    tab.st = mtWork + (blockIdx.x * blockDim.x + threadIdx.x);
-    const uint32_t total = (uint32_t)nItems * (uint32_t)chunk;
-    const bool stereo = C.stereoSeparation > 0;
+    tab.st = A.mtWork + (blockIdx.x * blockDim.x + threadIdx.x);
+    const int nItems = A.nItems, s0 = A.s0;
+    DStats* const st = A.st;
+    const uint32_t total = (uint32_t)nItems * (uint32_t)A.chunk;
+    const bool stereo = A.C.stereoSeparation > 0;
     const size_t N = (size_t)total * (stereo ? 2 : 1);
     bool ovf = false;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += gridDim.x * blockDim.x) {
+        const FRAY_RO WhShadeArgs* AP = kernel_args<WhShadeArgs>();
+        const DScene& S = KARG(WhShadeArgs, AP, S);
+        const DCamera& C = KARG(WhShadeArgs, AP, C);
+        const DFrame& F = KARG(WhShadeArgs, AP, F);
+        const WhittedQueue& Q = KARG(WhShadeArgs, AP, Q);
+        const uint32_t* const x397 = KARG(WhShadeArgs, AP, x397);
         const int item = (int)(slot % (uint32_t)nItems), s = (int)(slot / (uint32_t)nItems);
         int x, y;
         if (!item_pixel(F, item, x, y)) {                 // ragged edge bucket: nothing to shade, nothing to test
@@ -350,12 +389,18 @@ static __global__ __launch_bounds__(256, FRAY_WH_SHADE_WAVES) void k_wh_shade(DS
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
 
+struct WhVisibleArgs { DScene S; WhittedQueue Q; size_t N; int T; DStats* st; };
 template <int ST>
-static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_wh_visible(DScene S, WhittedQueue Q, size_t N, int T, DStats* st)
+static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_wh_visible(WhVisibleArgs A)
 {
     Cnt c = zero_cnt();
-    const size_t total = N * (size_t)T;
+    const size_t N = A.N;
+    DStats* const st = A.st;
+    const size_t total = N * (size_t)A.T;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const FRAY_RO WhVisibleArgs* AP = kernel_args<WhVisibleArgs>();
+        const DScene& S = KARG(WhVisibleArgs, AP, S);
+        const WhittedQueue& Q = KARG(WhVisibleArgs, AP, Q);
         const size_t e = t % N;
         if (!Q.hit[e]) continue;
         Q.vis[t] = visible<ST>(S, v3(Q.ax[e], Q.ay[e], Q.az[e]), v3(Q.bx[t], Q.by[t], Q.bz[t]), c) ? 1 : 0;
@@ -659,12 +704,16 @@ FD void bounce_emit(const PathQueue& Qout, const ShadowQueue& SQ, uint32_t segBe
 // LONG: the generators are MtPath (paths that may draw more than 227 words, i.e. maxTraceDepth >= 20); `LR` says where a path's two
 // 624-word columns live and how to recompute its seed (slot -> pixel, sample).
 struct LongRng { uint32_t* cols; uint32_t nPaths; DFrame F; int nItems, s0; };
+struct BounceArgs { DScene S; PathQueue Qin, Qout; ShadowQueue SQ; QMetaRO metaIn; QMeta* metaOut; QMeta* metaShadow; TermBuf TB; StereoBuf SB; LongRng LR; DStats* st; };
 template <int ST, bool LONG>
-static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DScene S, PathQueue Qin, PathQueue Qout, ShadowQueue SQ, QMetaRO metaIn,
-                                                                          QMeta* metaOut, QMeta* metaShadow, TermBuf TB, StereoBuf SB, LongRng LR, DStats* st)
+static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(BounceArgs A)
 {
     typedef typename std::conditional<LONG, MtPath, Mt>::type G;
     Cnt c = zero_cnt();
+    const QMetaRO metaIn = A.metaIn;
+    QMeta* const metaOut = A.metaOut;
+    QMeta* const metaShadow = A.metaShadow;
+    DStats* const st = A.st;
     const FRAY_RO uint32_t* off = metaIn.p->off;
     const uint32_t nSeg = metaIn.p->nSeg, chunkIn = metaIn.p->chunk;
     const WaveShare ws = wave_share(metaIn.p->n);
@@ -675,6 +724,14 @@ static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DSc
     stamp_begin();
 #endif
     for (uint32_t base = ws.begin; base < ws.end; base += 64u) {
+        const FRAY_RO BounceArgs* AP = kernel_args<BounceArgs>();
+        const DScene& S = KARG(BounceArgs, AP, S);
+        const PathQueue& Qin = KARG(BounceArgs, AP, Qin);
+        const PathQueue& Qout = KARG(BounceArgs, AP, Qout);
+        const ShadowQueue& SQ = KARG(BounceArgs, AP, SQ);
+        const TermBuf& TB = KARG(BounceArgs, AP, TB);
+        const StereoBuf& SB = KARG(BounceArgs, AP, SB);
+        const LongRng& LR = KARG(BounceArgs, AP, LR);
         const uint32_t di = base + lane;
         bool cont = false, shadow = false;
         V3 sa, sb;
@@ -717,10 +774,13 @@ static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(DSc
 
 // visible() for every queued next-event segment (main.cpp:64-80, 143-144): the sample's term of this bounce is the
 // segment's radiance if it is unobstructed, black otherwise.
+struct ShadowArgs { DScene S; ShadowQueue SQ; QMetaRO meta; TermBuf TB; DStats* st; };
 template <int ST>
-static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(DScene S, ShadowQueue SQ, QMetaRO meta, TermBuf TB, DStats* st)
+static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(ShadowArgs A)
 {
     Cnt c = zero_cnt();
+    const QMetaRO meta = A.meta;
+    DStats* const st = A.st;
     const FRAY_RO uint32_t* off = meta.p->off;
     const uint32_t nSeg = meta.p->nSeg, chunkIn = meta.p->chunk;
     const WaveShare ws = wave_share(meta.p->n);
@@ -731,6 +791,10 @@ static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(DSc
     stamp_begin();
 #endif
     for (uint32_t base = ws.begin; base < ws.end; base += 64u) {
+        const FRAY_RO ShadowArgs* AP = kernel_args<ShadowArgs>();
+        const DScene& S = KARG(ShadowArgs, AP, S);
+        const ShadowQueue& SQ = KARG(ShadowArgs, AP, SQ);
+        const TermBuf& TB = KARG(ShadowArgs, AP, TB);
         const uint32_t di = base + lane;
         const bool live = di < ws.end;
         const uint32_t i = seg_map(off, nSeg, chunkIn, base, di, live, seg);

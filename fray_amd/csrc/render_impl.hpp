@@ -87,7 +87,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
         if (nItems > 0) {
             hipEvent_t a = pool_event(sc->evPool, 0), b = pool_event(sc->evPool, 1);
             HIP_TRY(hipEventRecord(a, stream));
-            hipLaunchKernelGGL(k_primary<ST>, dim3(persistent_grid(nItems, FRAY_PRIMARY_WAVES)), dim3(256), 0, stream, S, C, F, nItems, d_id, d_dist, sc->d_stats, cursors);
+            hipLaunchKernelGGL(k_primary<ST>, dim3(persistent_grid(nItems, FRAY_PRIMARY_WAVES)), dim3(256), 0, stream, PrimaryArgs{S, C, F, nItems, d_id, d_dist, sc->d_stats, cursors});
             HIP_TRY(hipEventRecord(b, stream));
             nTraceEvents = 2;
         }
@@ -109,7 +109,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 hipEvent_t a = pool_event(sc->evPool, 0), b = pool_event(sc->evPool, 1);
                 if (!a || !b) return FRAYHIP_E_NOMEM;
                 HIP_TRY(hipEventRecord(a, stream));
-                hipLaunchKernelGGL(k_whitted<ST>, dim3(grid), dim3(256), 0, stream, S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats, cursors);
+                hipLaunchKernelGGL(k_whitted<ST>, dim3(grid), dim3(256), 0, stream, WhittedArgs{S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats, cursors});
                 HIP_TRY(hipEventRecord(b, stream));
                 nTraceEvents = 2;
             } else if (nItems > 0) {
@@ -154,11 +154,11 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
                     if (!ea || !eb || !ec || !ed) return FRAYHIP_E_NOMEM;
                     HIP_TRY(hipEventRecord(ea, stream));
-                    hipLaunchKernelGGL(k_wh_shade<ST>, dim3(grid), dim3(256), 0, stream, S, C, F, nItems, s0, cn, Q, mtWork, x397, sc->d_stats);
+                    hipLaunchKernelGGL(k_wh_shade<ST>, dim3(grid), dim3(256), 0, stream, WhShadeArgs{S, C, F, nItems, s0, cn, Q, mtWork, x397, sc->d_stats});
                     HIP_TRY(hipEventRecord(eb, stream));
                     nTraceEvents += 2;
                     HIP_TRY(hipEventRecord(ec, stream));
-                    if (T > 0) hipLaunchKernelGGL(k_wh_visible<ST>, dim3(grid_for(bN * (size_t)T)), dim3(256), 0, stream, S, Q, bN, T, sc->d_stats + 1);
+                    if (T > 0) hipLaunchKernelGGL(k_wh_visible<ST>, dim3(grid_for(bN * (size_t)T)), dim3(256), 0, stream, WhVisibleArgs{S, Q, bN, T, sc->d_stats + 1});
                     HIP_TRY(hipEventRecord(ed, stream));
                     nShadowEvents += 2;
                     hipLaunchKernelGGL(k_wh_gather, dim3(grid_for(bN)), dim3(256), 0, stream, S, Q, bN, bs, radL, radR);
@@ -253,17 +253,14 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                         HIP_TRY(hipEventRecord(ea, ls));
                         const LongRng LR{L.mtCols, (uint32_t)nPaths, F, nItems, s0};
                         const TermBuf TB{L.terms, L.termCount, (uint32_t)nPaths, b};
-                        if (longRng)
-                            hipLaunchKernelGGL((k_pt_bounce<ST, true>), dim3(grid), dim3(256), 0, ls, S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ,
-                                               mIn, L.meta + ((b + 1) & 1), L.meta + 2, TB, save, LR, sc->d_stats);
-                        else
-                            hipLaunchKernelGGL((k_pt_bounce<ST, false>), dim3(grid), dim3(256), 0, ls, S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ,
-                                               mIn, L.meta + ((b + 1) & 1), L.meta + 2, TB, save, LR, sc->d_stats);
+                        const BounceArgs BA{S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ, mIn, L.meta + ((b + 1) & 1), L.meta + 2, TB, save, LR, sc->d_stats};
+                        if (longRng) hipLaunchKernelGGL((k_pt_bounce<ST, true>), dim3(grid), dim3(256), 0, ls, BA);
+                        else hipLaunchKernelGGL((k_pt_bounce<ST, false>), dim3(grid), dim3(256), 0, ls, BA);
                         HIP_TRY(hipEventRecord(eb, ls));
                         nTraceEvents += 2;
                         hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, ls, L.meta + ((b + 1) & 1), L.meta + 2);
                         HIP_TRY(hipEventRecord(ec, ls));
-                        hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid), dim3(256), 0, ls, S, L.SQ, mSh, TB, sc->d_stats + 1);
+                        hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid), dim3(256), 0, ls, ShadowArgs{S, L.SQ, mSh, TB, sc->d_stats + 1});
                         HIP_TRY(hipEventRecord(ed, ls));
                         nShadowEvents += 2;
                     }

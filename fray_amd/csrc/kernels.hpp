@@ -31,7 +31,7 @@
 #define FRAY_SHADOW_WAVES 5     // the any-hit kernels at 96 VGPRs (13 / 8 spilled): boxed Whitted 12.0 -> 11.3 ms, headline -1 % against 4 waves
 #endif
 #ifndef FRAY_BOUNCE_WAVES
-#define FRAY_BOUNCE_WAVES 3   // waves per SIMD the bounce kernel is register-allocated for
+#define FRAY_BOUNCE_WAVES 4   // waves per SIMD the bounce kernel is register-allocated for: 128 VGPRs, 2 spilled (3 waves: 129 VGPRs; headline 123.5 vs 116.2 ms)
 #endif
 
 // ---- kernel arguments, read where they are used ------------------------------------------------------------
@@ -640,7 +640,7 @@ FD WaveShare wave_share(uint32_t n)
 // (`cont`: ps is the path to continue).
 template <int ST, bool BARY, class G>
 FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitRec& h, const TermBuf& TB, DStats* st, const StereoBuf& SB, bool& cont, bool& shadow,
-                   V3& sa, V3& sb, C3& sc, Cnt& c)
+                   const ShadowQueue& SQ, uint32_t shadowBase, Cnt& c)
 {
     C3 own = c3(0, 0, 0);          // this bounce's term, unless a queued next-event segment will provide it
     if (h.node <= -2) {                                       // main.cpp:201-208
@@ -656,17 +656,29 @@ FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitRec& h, const Te
         finalize_hit<ST, BARY>(S, h, ps.o, ps.d, sh.usesUV || N.bumpTex >= 0, info);
         apply_bump<ST>(S, h.node, info, c);
         mt_skip(ps.tab, spawn_words(sh));                     // the discarded spawnRay (main.cpp:219-224)
-        shadow = nee_prepare(S, ps.d, info, ps.pm, sh, ps.rnd, ps.tab, sa, sb, sc);
+        {
+            // the next-event segment goes to the wave's shadow segment right here (ballot rank among the lanes that sampled a light), so
+            // that it is not carried in registers across the spawn; the wave's count is advanced by the caller (bounce_emit)
+            V3 sa, sb;
+            C3 sc;
+            shadow = nee_prepare(S, ps.d, info, ps.pm, sh, ps.rnd, ps.tab, sa, sb, sc);
+            const unsigned long long smask = __ballot(shadow);
+            if (shadow) {
+                const uint32_t j = shadowBase + (uint32_t)__popcll(smask & ((1ull << (threadIdx.x & 63u)) - 1ull));
+                SQ.ax[j] = sa.x; SQ.ay[j] = sa.y; SQ.az[j] = sa.z;
+                SQ.bx[j] = sb.x; SQ.by[j] = sb.y; SQ.bz[j] = sb.z;
+                SQ.cr[j] = sc.r; SQ.cg[j] = sc.g; SQ.cb[j] = sc.b;
+                SQ.slot[j] = ps.slot;
+            }
+        }
         PathRay win, wout;
         win.o = ps.o; win.d = ps.d; win.depth = ps.depth; win.flags = ps.flags;
         C3 brdf;
         float pdf;
         spawn_ray(sh, info, win, ps.tab, wout, brdf, pdf);
-        if (pdf == -1.0f || pdf == 0.0f) {                    // main.cpp:238-239: the sentinels return without the light contribution
-            own = pdf == -1.0f ? c3(1, 0, 0) : c3(0, 0, 0);
-            shadow = false;
-            path_finish(TB, st, ps, SB);
-        } else {
+        // main.cpp:238-239 returns without the light contribution when pdf is -1 or 0: no spawn_ray above produces either value
+        // (1 / 2 pi, 1e9, 1), so the segment queued above always stands
+        {
             ps.pm = ps.pm * brdf / pdf;
             ps.o = wout.o; ps.d = wout.d; ps.depth = wout.depth; ps.flags = wout.flags;
             // entry test of the next pathtrace() call (main.cpp:173-176): it returns black, this bounce's term stays the light contribution
@@ -680,22 +692,13 @@ FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitRec& h, const Te
 // Survivors and next-event segments of one batch of 64 paths go to the wave's own segments of the output queues
 // (ballot rank, no global counter).
 template <class G>
-FD void bounce_emit(const PathQueue& Qout, const ShadowQueue& SQ, uint32_t segBegin, uint32_t& produced, uint32_t& producedS, bool cont, bool shadow,
-                    const PathStateT<G>& ps, V3 sa, V3 sb, C3 sc)
+FD void bounce_emit(const PathQueue& Qout, uint32_t segBegin, uint32_t& produced, uint32_t& producedS, bool cont, bool shadow, const PathStateT<G>& ps)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long mask = __ballot(cont);
     if (cont) path_store(Qout, segBegin + produced + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), ps);
     produced += (uint32_t)__popcll(mask);
-    const unsigned long long smask = __ballot(shadow);
-    if (shadow) {
-        const uint32_t j = segBegin + producedS + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull));
-        SQ.ax[j] = sa.x; SQ.ay[j] = sa.y; SQ.az[j] = sa.z;
-        SQ.bx[j] = sb.x; SQ.by[j] = sb.y; SQ.bz[j] = sb.z;
-        SQ.cr[j] = sc.r; SQ.cg[j] = sc.g; SQ.cb[j] = sc.b;
-        SQ.slot[j] = ps.slot;
-    }
-    producedS += (uint32_t)__popcll(smask);
+    producedS += (uint32_t)__popcll(__ballot(shadow));       // the segments themselves were written by path_shade
 }
 
 // **Dominant kernel**: one pathtrace() iteration (main.cpp:171-244) for every live path of the queue: closest hit,
@@ -734,8 +737,6 @@ static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(Bou
         const LongRng& LR = KARG(BounceArgs, AP, LR);
         const uint32_t di = base + lane;
         bool cont = false, shadow = false;
-        V3 sa, sb;
-        C3 sc;
         PathStateT<G> ps;
         bool live = di < ws.end;
         const uint32_t i = seg_map(off, nSeg, chunkIn, base, di, live, seg);
@@ -757,10 +758,10 @@ static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(Bou
                 ps.tab.col = LR.cols + (size_t)624 * LR.nPaths + ps.slot;
             }
             STAMP(8);
-            path_shade<ST, false>(S, ps, h, TB, st, SB, cont, shadow, sa, sb, sc, c);
+            path_shade<ST, false>(S, ps, h, TB, st, SB, cont, shadow, SQ, ws.begin + producedS, c);
             STAMP(10);
         }
-        bounce_emit(Qout, SQ, ws.begin, produced, producedS, cont, shadow, ps, sa, sb, sc);
+        bounce_emit(Qout, ws.begin, produced, producedS, cont, shadow, ps);
         STAMP(13);
     }
 #ifdef FRAY_STAMPS

@@ -215,6 +215,7 @@ static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(Whit
     const int nItems = A.nItems;
     DCursors* const cur = A.cur;
     DStats* const st = A.st;
+    __shared__ double rightRay[6][256];
     for (int r = 0, item = claim_items(cur, nItems, r); item < nItems; item = claim_items(cur, nItems, r)) {
         const FRAY_RO WhittedArgs* AP = kernel_args<WhittedArgs>();
         const DScene& S = KARG(WhittedArgs, AP, S);
@@ -235,13 +236,30 @@ static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(Whit
             if (F.jitter) { ox = rng_float(rnd); oy = rng_float(rnd); }
             else { ox = (float)kAAOffsets[i][0]; oy = (float)kAAOffsets[i][1]; }
             double fx = (double)((float)x + ox), fy = (double)((float)y + oy);   // int + float, main.cpp:359
-            if (C.stereoSeparation > 0) {                     // raytraceSinglePixel, main.cpp:306-317
-                V3 ol, dl, orr, dr;
-                if (C.dof) { dof_ray(C, fx, fy, tab, ol, dl, 1); dof_ray(C, fx, fy, tab, orr, dr, 2); }
-                else { screen_ray(C, fx, fy, ol, dl, 1); screen_ray(C, fx, fy, orr, dr, 2); }
+            const bool stereo = C.stereoSeparation > 0;
+            V3 o, d;
+            if (stereo) {                                     // raytraceSinglePixel, main.cpp:306-317: both rays first, then left, then right
+                V3 orr, dr;
+                if (C.dof) { dof_ray(C, fx, fy, tab, o, d, 1); dof_ray(C, fx, fy, tab, orr, dr, 2); }
+                else { screen_ray(C, fx, fy, o, d, 1); screen_ray(C, fx, fy, orr, dr, 2); }
+                // the right eye's ray waits in LDS (the thread's own slots) while the left eye's tree is walked
+                rightRay[0][threadIdx.x] = orr.x; rightRay[1][threadIdx.x] = orr.y; rightRay[2][threadIdx.x] = orr.z;
+                rightRay[3][threadIdx.x] = dr.x; rightRay[4][threadIdx.x] = dr.y; rightRay[5][threadIdx.x] = dr.z;
                 bump<ST>(c.samples, 2);
-                C3 cl = raytrace_full<ST, MtLong>(S, ol, dl, tab, c, ovf);
-                C3 cr = raytrace_full<ST, MtLong>(S, orr, dr, tab, c, ovf);
+            } else {
+                if (C.dof) dof_ray(C, fx, fy, tab, o, d); else screen_ray(C, fx, fy, o, d);
+                bump<ST>(c.samples);
+            }
+            C3 cl = c3(0, 0, 0), cr = c3(0, 0, 0);
+            for (int eye = 0; eye < (stereo ? 2 : 1); eye++) {      // one copy of the integrator for both eyes
+                if (eye == 1) {
+                    o = v3(rightRay[0][threadIdx.x], rightRay[1][threadIdx.x], rightRay[2][threadIdx.x]);
+                    d = v3(rightRay[3][threadIdx.x], rightRay[4][threadIdx.x], rightRay[5][threadIdx.x]);
+                }
+                const C3 v = raytrace_full<ST, MtLong>(S, o, d, tab, c, ovf);
+                if (eye == 0) cl = v; else cr = v;
+            }
+            if (stereo) {
                 if (S.saturation != 1) {                      // Color::adjustSaturation, color.h:127-133
                     float ml = (cl.r + cl.g + cl.b) / 3.0f, mr = (cr.r + cr.g + cr.b) / 3.0f;
                     cl = c3(ml + (cl.r - ml) * S.saturation, ml + (cl.g - ml) * S.saturation, ml + (cl.b - ml) * S.saturation);
@@ -249,10 +267,7 @@ static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(Whit
                 }
                 avg = avg + (cl * ldc(C.leftMask) + cr * ldc(C.rightMask));
             } else {
-                V3 o, d;
-                if (C.dof) dof_ray(C, fx, fy, tab, o, d); else screen_ray(C, fx, fy, o, d);
-                bump<ST>(c.samples);
-                avg = avg + raytrace_full<ST, MtLong>(S, o, d, tab, c, ovf);
+                avg = avg + cl;
             }
             ovf = ovf || rnd.j > 227;
         }
@@ -344,6 +359,7 @@ static __global__ __launch_bounds__(256, FRAY_WH_SHADE_WAVES) void k_wh_shade(Wh
     const bool stereo = A.C.stereoSeparation > 0;
     const size_t N = (size_t)total * (stereo ? 2 : 1);
     bool ovf = false;
+    __shared__ double rightRay[6][256];
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += gridDim.x * blockDim.x) {
         const FRAY_RO WhShadeArgs* AP = kernel_args<WhShadeArgs>();
         const DScene& S = KARG(WhShadeArgs, AP, S);
@@ -369,20 +385,27 @@ static __global__ __launch_bounds__(256, FRAY_WH_SHADE_WAVES) void k_wh_shade(Wh
         if (F.jitter) { ox = rng_float(rnd); oy = rng_float(rnd); }
         else { ox = (float)kAAOffsets[i][0]; oy = (float)kAAOffsets[i][1]; }
         const double fx = (double)((float)x + ox), fy = (double)((float)y + oy);   // int + float, main.cpp:359
+        V3 o, d;
         if (stereo) {                                     // raytraceSinglePixel, main.cpp:306-317: both rays first, then left, then right
-            V3 ol, dl, orr, dr;
-            if (C.dof) { dof_ray(C, fx, fy, tab, ol, dl, 1); dof_ray(C, fx, fy, tab, orr, dr, 2); }
-            else { screen_ray(C, fx, fy, ol, dl, 1); screen_ray(C, fx, fy, orr, dr, 2); }
+            V3 orr, dr;
+            if (C.dof) { dof_ray(C, fx, fy, tab, o, d, 1); dof_ray(C, fx, fy, tab, orr, dr, 2); }
+            else { screen_ray(C, fx, fy, o, d, 1); screen_ray(C, fx, fy, orr, dr, 2); }
+            // the right eye's ray waits in LDS (the thread's own slots) while the left eye is traced and shaded: no register holds it
+            rightRay[0][threadIdx.x] = orr.x; rightRay[1][threadIdx.x] = orr.y; rightRay[2][threadIdx.x] = orr.z;
+            rightRay[3][threadIdx.x] = dr.x; rightRay[4][threadIdx.x] = dr.y; rightRay[5][threadIdx.x] = dr.z;
             bump<ST>(c.samples, 2);
-            wh_shade_eye<ST>(S, ol, dl, tab, Q, N, slot, c);
-            wh_shade_eye<ST>(S, orr, dr, tab, Q, N, (size_t)total + slot, c);
         } else {
-            V3 o, d;
             if (C.dof) dof_ray(C, fx, fy, tab, o, d); else screen_ray(C, fx, fy, o, d);
             bump<ST>(c.samples);
-            wh_shade_eye<ST>(S, o, d, tab, Q, N, slot, c);
         }
         ovf = ovf || rnd.j > 227;
+        for (int eye = 0; eye < (stereo ? 2 : 1); eye++) {          // one copy of the trace-and-shade code for both eyes
+            if (eye == 1) {
+                o = v3(rightRay[0][threadIdx.x], rightRay[1][threadIdx.x], rightRay[2][threadIdx.x]);
+                d = v3(rightRay[3][threadIdx.x], rightRay[4][threadIdx.x], rightRay[5][threadIdx.x]);
+            }
+            wh_shade_eye<ST>(S, o, d, tab, Q, N, (size_t)eye * total + slot, c);
+        }
     }
     if (ovf) atomicAdd(&st->rngOverflow, 1ull);
     if (ST & 1) flush_stats(st, c);

@@ -113,6 +113,7 @@ int persistent_grid(size_t n, int wavesPerSimd)
 #ifndef FRAY_BOUNCE_BLOCKS
 #define FRAY_BOUNCE_BLOCKS 2048
 #endif
+static_assert(FRAY_BOUNCE_BLOCKS * 4 <= FRAY_MAXSEG, "every wave of the bounce / shadow grid owns one segment of the queue tables (QMeta)");
 int bounce_grid(size_t n)
 {
     size_t blocks = (n + 255) / 256;

@@ -225,6 +225,17 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag[0]) == 1:
+            # one exchange of the (still empty) frame before anything is timed: a transport that raises on its first use is replaced
+            # by the other one on EVERY rank, like one that cannot be set up
+            try:
+                libgather.gather(frame)
+                torch.cuda.synchronize()
+            except Exception as e:                 # noqa: BLE001
+                sys.stderr.write("rank %d: library gather failed on its first exchange (%s)\n" % (rank, e))
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
             gatherer = gather_ids = gather_dist = libgather
             transport = "frayhip_gather_buckets (RCCL ncclSend/ncclRecv, peer -> root)"
         else:

@@ -175,7 +175,10 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             // Batches of `chunk` samples per pixel; up to FRAY_PT_LANES batches are in flight at once, each on its own
             // stream with its own queues, so one batch's launch gaps, scans and kernel tails are filled by the others'
             // blocks.  Only the resolves are ordered (evResolved): the per-pixel sum runs in sample order.
-            const int maxLanes = std::max(1, std::min(sc->ptLanes, FRAY_PT_LANES));
+            int maxLanes = std::max(1, std::min(sc->ptLanes, FRAY_PT_LANES));
+            // a small frame (an eighth of 1080p x 64 spp, i.e. one rank's share of an 8-rank run) is cut into fewer, larger batches:
+            // measured 15.5 ms on three lanes against 15.9 on four; from a quarter of that frame upwards four lanes win
+            if (maxLanes > 3 && (size_t)nItems * (size_t)spp < ((size_t)24 << 20)) maxLanes = 3;
             const size_t budget = std::max<size_t>(sc->ptBudgetBytes / perPath, 1);       // paths in flight over all lanes
             int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / maxLanes / (size_t)nItems);
             if (chunk > spp) chunk = spp;

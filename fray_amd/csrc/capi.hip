@@ -369,6 +369,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         put3(M.bmax, m.bbox_max);
         M.nTris = m.n_triangles;
         M.hasKd = m.has_kd;
+        if (m.has_kd) sc->kdMeshes = true;
         M.smooth = !(m.faceted || m.n_normals == 0);
         M.culling = m.backfaceCulling;
         M.hasUV = m.n_uvs != 0;
@@ -605,6 +606,7 @@ int frayhip_render_device(frayhip_scene* s, const frayhip_frame* f, float* d_rgb
     hipStream_t stream = (hipStream_t)hip_stream;
     const bool stats = (f->flags & FRAYHIP_FRAME_STATS) != 0;
     if (s->extGeometry) return stats ? frayhip_detail::render_impl<3>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st) : frayhip_detail::render_impl<2>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st);
+    if (s->kdMeshes) return stats ? frayhip_detail::render_impl<5>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st) : frayhip_detail::render_impl<4>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st);
     return stats ? frayhip_detail::render_impl<1>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st) : frayhip_detail::render_impl<0>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st);
 }
 

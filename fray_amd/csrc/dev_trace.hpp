@@ -21,6 +21,9 @@ struct Cnt {
 // Template flag word of the trace / shade code: bit 0 = maintain the work counters, bit 1 = the scene
 // has Cube / CSG geometry (kept out of the common kernels: its hit lists live in scratch memory).
 template <int ST> FD void bump(unsigned long long& c, unsigned long long n = 1) { if (ST & 1) c += n; }
+// Kernel flag word: bit 0 = maintain the work counters, bit 1 = the scene has Cube / CSG geometry, bit 2 = it has meshes with a KD-tree.
+// The KD walk (and its 40-odd registers) is compiled only into the variants that need it: bit 2, or bit 1 (a CSG operand may be a KD mesh).
+constexpr bool kd_variant(int st) { return (st & 6) != 0; }
 
 // Closest-hit record.  Shading attributes (ip, normal, uv, dNdx/dNdy) are re-derived from it for
 // the winning node only (finalize_hit in dev_shade.hpp) -- same arithmetic, so same bits.
@@ -514,6 +517,8 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, LocalRay& lr, V3
             if (tri_test<ST>(tris + i, culling, ls, ld, gamma, l2, l3, c)) { found = true; tri = i; }
         STAMP(3);
         if (!found) return false;
+    } else if (!kd_variant(ST)) {
+        return false;        // a mesh with a KD-tree in a scene uploaded as having none: cannot happen (frayhip_scene_create picks the variant)
     } else if (!mesh_intersect<ST>(S.meshes[N.geomIndex], lr, gamma, tri, l2, l3, c)) return false;
     ipl = ls + ld * gamma;
     t = gamma;

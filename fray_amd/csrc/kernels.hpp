@@ -33,6 +33,9 @@
 #ifndef FRAY_BOUNCE_WAVES
 #define FRAY_BOUNCE_WAVES 4   // waves per SIMD the bounce kernel is register-allocated for: 128 VGPRs, 2 spilled (3 waves: 129 VGPRs; headline 123.5 vs 116.2 ms)
 #endif
+#ifndef FRAY_BOUNCE_WAVES_NOKD
+#define FRAY_BOUNCE_WAVES_NOKD 5   // the variants without the KD walk need 106 VGPRs: 5 waves/SIMD at 96 with 7 spilled (headline 111.8 -> 108.7 ms against 4 waves)
+#endif
 
 // ---- kernel arguments, read where they are used ------------------------------------------------------------
 // A kernel's by-value arguments are all loaded at its entry and kept alive; in the big kernels most of them (scene tables, queue
@@ -732,7 +735,7 @@ FD void bounce_emit(const PathQueue& Qout, uint32_t segBegin, uint32_t& produced
 struct LongRng { uint32_t* cols; uint32_t nPaths; DFrame F; int nItems, s0; };
 struct BounceArgs { DScene S; PathQueue Qin, Qout; ShadowQueue SQ; QMetaRO metaIn; QMeta* metaOut; QMeta* metaShadow; TermBuf TB; StereoBuf SB; LongRng LR; DStats* st; };
 template <int ST, bool LONG>
-static __global__ __launch_bounds__(256, FRAY_BOUNCE_WAVES) void k_pt_bounce(BounceArgs A)
+static __global__ __launch_bounds__(256, kd_variant(ST) ? FRAY_BOUNCE_WAVES : FRAY_BOUNCE_WAVES_NOKD) void k_pt_bounce(BounceArgs A)
 {
     typedef typename std::conditional<LONG, MtPath, Mt>::type G;
     Cnt c = zero_cnt();

@@ -49,6 +49,7 @@ struct frayhip_scene {
     bool whittedNeedsRecursion = false;
     int lightSampleCount = 0;         // sum over lights of Light::getNumSamples(): segments a Lambert / Phong hit queues (wavefront Whitted)
     bool extGeometry = false;         // Cube / CSG nodes present
+    bool kdMeshes = false;            // some mesh has a KD-tree: selects the <ST | 4> kernel variants (the others are compiled without the KD walk)
     // per-frame workspace, grown on demand and kept between frames
     void* d_work = nullptr;
     size_t work_bytes = 0;
@@ -84,5 +85,7 @@ extern template int render_impl<0>(frayhip_scene*, const frayhip_frame*, float*,
 extern template int render_impl<1>(frayhip_scene*, const frayhip_frame*, float*, int32_t*, double*, hipStream_t, frayhip_stats*);
 extern template int render_impl<2>(frayhip_scene*, const frayhip_frame*, float*, int32_t*, double*, hipStream_t, frayhip_stats*);
 extern template int render_impl<3>(frayhip_scene*, const frayhip_frame*, float*, int32_t*, double*, hipStream_t, frayhip_stats*);
+extern template int render_impl<4>(frayhip_scene*, const frayhip_frame*, float*, int32_t*, double*, hipStream_t, frayhip_stats*);
+extern template int render_impl<5>(frayhip_scene*, const frayhip_frame*, float*, int32_t*, double*, hipStream_t, frayhip_stats*);
 
 }  // namespace frayhip_detail

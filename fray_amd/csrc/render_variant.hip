@@ -1,9 +1,9 @@
-// One instantiation of render_impl<ST> per translation unit (the Makefile compiles this file four
-// times, -DFRAY_ST=0..3), so the kernel variants build in parallel.
+// One instantiation of render_impl<ST> per translation unit (the Makefile compiles this file six
+// times, -DFRAY_ST=0..5), so the kernel variants build in parallel.
 #include "render_impl.hpp"
 
 #ifndef FRAY_ST
-#error "compile with -DFRAY_ST=0..3"
+#error "compile with -DFRAY_ST=0..5"
 #endif
 
 namespace frayhip_detail {

@@ -16,9 +16,9 @@ CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off $(INC)
 
 HOST_SRC := fray_amd/csrc/host_scene.cpp fray_amd/csrc/host_loaders.cpp fray_amd/csrc/host_exr.cpp fray_amd/csrc/capi_host.cpp
 HOST_OBJ := $(HOST_SRC:.cpp=.o)
-# render_variant.hip is compiled once per kernel flag word (render_impl<0..5>): six independent translation
+# render_variant.hip is compiled once per kernel flag word (render_impl<0..5, 8, 9>): eight independent translation
 # units that `make -j` builds side by side
-VARIANT_OBJ := $(foreach st,0 1 2 3 4 5,fray_amd/csrc/variant$(st).o)
+VARIANT_OBJ := $(foreach st,0 1 2 3 4 5 8 9,fray_amd/csrc/variant$(st).o)
 HIP_OBJ  := fray_amd/csrc/capi.o fray_amd/csrc/capi_comm.o $(VARIANT_OBJ)
 HIP_HDR  := $(wildcard fray_amd/csrc/*.h) $(wildcard fray_amd/csrc/*.hpp) include/frayhip.h
 

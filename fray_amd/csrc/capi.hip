@@ -528,6 +528,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     S.textures = (const FRAY_RO DTexture*)(base + oTex);
     S.lights = (const FRAY_RO DLight*)(base + oLights);
     S.env.present = d.environment.present;
+    if (d.n_textures > 0 || (d.environment.present && d.environment.loaded)) sc->textured = true;
     S.env.loaded = d.environment.loaded;
     for (int f = 0; f < 6; f++) {
         S.env.width[f] = d.environment.width[f];
@@ -607,6 +608,7 @@ int frayhip_render_device(frayhip_scene* s, const frayhip_frame* f, float* d_rgb
     const bool stats = (f->flags & FRAYHIP_FRAME_STATS) != 0;
     if (s->extGeometry) return stats ? frayhip_detail::render_impl<3>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st) : frayhip_detail::render_impl<2>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st);
     if (s->kdMeshes) return stats ? frayhip_detail::render_impl<5>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st) : frayhip_detail::render_impl<4>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st);
+    if (s->textured) return stats ? frayhip_detail::render_impl<9>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st) : frayhip_detail::render_impl<8>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st);
     return stats ? frayhip_detail::render_impl<1>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st) : frayhip_detail::render_impl<0>(s, f, d_rgb, d_hit_id, d_hit_dist, stream, st);
 }
 

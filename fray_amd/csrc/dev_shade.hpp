@@ -64,7 +64,8 @@ template <int ST, bool BARY = false>
 FD void finalize_hit(const DScene& S, const HitRec& h, V3 o, V3 d, bool needUV, HitInfo& info)
 {
     const FRAY_RO DNode& N = S.nodes[h.node];
-    const bool needBump = N.bumpTex >= 0;
+    needUV = needUV && tex_variant(ST);                       // no texture in the scene reads (u, v)
+    const bool needBump = tex_variant(ST) && N.bumpTex >= 0;
     V3 ls = mulM(o - ld3(N.T.off), N.T.inv);
     V3 ldir = normalized(mulM(d, N.T.inv));
     V3 ipl = ls + ldir * h.t;
@@ -125,6 +126,7 @@ FD float fresnel_schlick(V3 i, V3 n, float ior)   // shading.cpp:230-236
 template <int ST>
 FD C3 texture_sample(const DScene& S, int t, V3 rayDir, const HitInfo& info, Cnt& c)
 {
+    if (!tex_variant(ST)) return c3(1, 1, 1);                 // never reached: the scene has no texture
     const FRAY_RO DTexture& T = S.textures[t];
     if (T.kind == 0) {   // CheckerTexture::sample, shading.cpp:40-46
         int ix = int(floor(info.u * T.scaling) / 5.0);
@@ -150,6 +152,7 @@ FD C3 texture_sample(const DScene& S, int t, V3 rayDir, const HitInfo& info, Cnt
 template <int ST>
 FD void apply_bump(const DScene& S, int nodeIdx, HitInfo& info, Cnt& c)
 {
+    if (!tex_variant(ST)) return;
     int bt = S.nodes[nodeIdx].bumpTex;
     if (bt < 0) return;
     const FRAY_RO DTexture& T = S.textures[bt];
@@ -167,7 +170,7 @@ FD void apply_bump(const DScene& S, int nodeIdx, HitInfo& info, Cnt& c)
 template <int ST>
 FD C3 environment(const DScene& S, V3 dir, Cnt& c)
 {
-    if (!S.env.present || !S.env.loaded) return c3(0, 0, 0);
+    if (!tex_variant(ST) || !S.env.present || !S.env.loaded) return c3(0, 0, 0);
     double maxVal = fabs(dir.x);
     int dim = 0;
     if (fabs(dir.y) > maxVal) { dim = 1; maxVal = fabs(dir.y); }

@@ -21,9 +21,13 @@ struct Cnt {
 // Template flag word of the trace / shade code: bit 0 = maintain the work counters, bit 1 = the scene
 // has Cube / CSG geometry (kept out of the common kernels: its hit lists live in scratch memory).
 template <int ST> FD void bump(unsigned long long& c, unsigned long long n = 1) { if (ST & 1) c += n; }
-// Kernel flag word: bit 0 = maintain the work counters, bit 1 = the scene has Cube / CSG geometry, bit 2 = it has meshes with a KD-tree.
+// Kernel flag word: bit 0 = maintain the work counters, bit 1 = the scene has Cube / CSG geometry, bit 2 = it has meshes with a KD-tree,
+// bit 3 = it has textures or an environment map.
 // The KD walk (and its 40-odd registers) is compiled only into the variants that need it: bit 2, or bit 1 (a CSG operand may be a KD mesh).
 constexpr bool kd_variant(int st) { return (st & 6) != 0; }
+// bit 3 = the scene has textures (bitmap, checker, Fresnel, bump) or a loaded environment map; the variants without it (and without bits 1 / 2,
+// which imply it) are compiled without texture sampling, bump mapping, the cubemap lookup and the sphere's uv (atan2 / asin)
+constexpr bool tex_variant(int st) { return (st & 14) != 0; }
 
 // Closest-hit record.  Shading attributes (ip, normal, uv, dNdx/dNdy) are re-derived from it for
 // the winning node only (finalize_hit in dev_shade.hpp) -- same arithmetic, so same bits.

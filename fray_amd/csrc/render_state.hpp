@@ -49,6 +49,7 @@ struct frayhip_scene {
     bool whittedNeedsRecursion = false;
     int lightSampleCount = 0;         // sum over lights of Light::getNumSamples(): segments a Lambert / Phong hit queues (wavefront Whitted)
     bool extGeometry = false;         // Cube / CSG nodes present
+    bool textured = false;            // textures or a loaded environment map present: selects the <ST | 8> variants when neither bit 1 nor bit 2 is set
     bool kdMeshes = false;            // some mesh has a KD-tree: selects the <ST | 4> kernel variants (the others are compiled without the KD walk)
     // per-frame workspace, grown on demand and kept between frames
     void* d_work = nullptr;
@@ -87,5 +88,7 @@ extern template int render_impl<2>(frayhip_scene*, const frayhip_frame*, float*,
 extern template int render_impl<3>(frayhip_scene*, const frayhip_frame*, float*, int32_t*, double*, hipStream_t, frayhip_stats*);
 extern template int render_impl<4>(frayhip_scene*, const frayhip_frame*, float*, int32_t*, double*, hipStream_t, frayhip_stats*);
 extern template int render_impl<5>(frayhip_scene*, const frayhip_frame*, float*, int32_t*, double*, hipStream_t, frayhip_stats*);
+extern template int render_impl<8>(frayhip_scene*, const frayhip_frame*, float*, int32_t*, double*, hipStream_t, frayhip_stats*);
+extern template int render_impl<9>(frayhip_scene*, const frayhip_frame*, float*, int32_t*, double*, hipStream_t, frayhip_stats*);
 
 }  // namespace frayhip_detail

@@ -671,3 +671,103 @@ def test_path_tracing_past_227_random_words_per_sample(fray, abi, oracle, gpu, d
     img2, _ = s.render(seed=42)
     assert np.array_equal(img, img2)
     s.close()
+
+
+# Kernel variant <8>: textures and an environment-free scene WITHOUT KD-tree meshes and without Cube / CSG (planes, spheres, a tree-less mesh;
+# checker texture on a plane and on the sphere, whose uv come from atan2 / asin).  The variants <0> (cornell_box, smallpt) and <4> / <2>
+# (everything else) are covered by the other tests; this one pins the fourth flag combination.
+TEXTURED_PLAIN_SCENE = """
+GlobalSettings {
+	frameWidth 96
+	frameHeight 72
+	ambientLight (0.15, 0.15, 0.2)
+	maxTraceDepth 4
+	wantAA off
+	%s
+}
+Camera camera {
+	position (0, 6, -18)
+	pitch -12
+	fov 60
+}
+RectLight l1 {
+	translate (2, 16, -4)
+	scale (6, 6, 6)
+	power 40
+	xSubd 2
+	ySubd 2
+}
+CheckerTexture chk {
+	color1 (0.8, 0.7, 0.2)
+	color2 (0.1, 0.2, 0.6)
+	scaling 0.5
+}
+CheckerTexture chk2 {
+	color1 (0.9, 0.9, 0.9)
+	color2 (0.2, 0.6, 0.3)
+	scaling 24
+}
+Lambert floorShader {
+	color (1, 1, 1)
+	texture chk
+}
+Lambert ballShader {
+	color (1, 1, 1)
+	texture chk2
+}
+Lambert plateShader {
+	color (0.7, 0.3, 0.2)
+}
+Plane floor {
+	y 0
+	limit 60
+}
+Sphere ball {
+	O (0, 0, 0)
+	R 3
+}
+Mesh plates {
+	file "%s"
+	faceted true
+	useKDTree false
+}
+Node floorNode {
+	geometry floor
+	shader floorShader
+}
+Node ballNode {
+	geometry ball
+	shader ballShader
+	translate (-3, 3, 2)
+	rotate (20, 35, 0)
+}
+Node platesNode {
+	geometry plates
+	shader plateShader
+	translate (5, 2, 0)
+	scale (2, 2, 2)
+}
+"""
+
+
+@pytest.mark.parametrize("gi", [0, 1])
+def test_textured_scene_without_kd_meshes_vs_oracle(fray, abi, oracle, gpu, tmp_path, gi):
+    import shutil
+    shutil.copy(os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenes", "plates.obj"), tmp_path / "plates.obj")   # files are looked up next to the scene
+    f = tmp_path / "textured_plain.fray"
+    f.write_text(TEXTURED_PLAIN_SCENE % ("gi on\n\tpathsPerPixel 8" if gi else "gi off", "plates.obj"))
+    s = fray.Scene.parseScene(str(f))
+    s.beginRender()
+    d = s.desc
+    assert d.n_textures == 2 and not any(d.meshes[i].has_kd for i in range(d.n_meshes))     # the <8> variants' scene class
+    img, st = s.render(seed=42, stats=True)
+    plain = s.render(seed=42)
+    plain = plain[0] if isinstance(plain, tuple) else plain
+    ref, ost = oracle.render(s.desc, abi.MODE_RENDER, seed=42)
+    assert ref.mean() > 0.02 and np.all(np.isfinite(img))
+    assert np.array_equal(img, plain)                              # counting (<9>) and plain (<8>) kernels draw the same picture
+    assert np.all(rms(img, ref) <= RMS_TOL), rms(img, ref)
+    assert float((img == ref).all(axis=2).mean()) >= 0.995
+    for k in ("samples", "closest_rays", "shadow_rays"):
+        assert st[k] == ost[k], k
+    s.close()

@@ -17,7 +17,7 @@ $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -mllvm -disable-machine-licm \
   -I$ROOT/include -I$ROOT/fray_amd/csrc "$@" -c $ROOT/fray_amd/csrc/capi.hip -o $OUT/capi.o
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libfrayhip.so $OUT/capi.o $OUT/variant0.o $ROOT/fray_amd/csrc/capi_comm.o -ldl \
-  $ROOT/fray_amd/csrc/variant1.o $ROOT/fray_amd/csrc/variant2.o $ROOT/fray_amd/csrc/variant3.o $ROOT/fray_amd/csrc/variant4.o $ROOT/fray_amd/csrc/variant5.o \
+  $ROOT/fray_amd/csrc/variant1.o $ROOT/fray_amd/csrc/variant2.o $ROOT/fray_amd/csrc/variant3.o $ROOT/fray_amd/csrc/variant4.o $ROOT/fray_amd/csrc/variant5.o $ROOT/fray_amd/csrc/variant8.o $ROOT/fray_amd/csrc/variant9.o \
   $ROOT/fray_amd/csrc/host_scene.o $ROOT/fray_amd/csrc/host_loaders.o $ROOT/fray_amd/csrc/host_exr.o $ROOT/fray_amd/csrc/capi_host.o
 python3 $ROOT/tools/kernel_resources.py $OUT/variant0.resources.txt > $OUT/resources.txt
 echo "built $OUT/libfrayhip.so"

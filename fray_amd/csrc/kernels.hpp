@@ -1,17 +1,22 @@
-// HIP kernels of the renderer (gfx950, wave64).
+// HIP kernels of the renderer (gfx950, wave64).  Every kernel template is compiled per flag word ST (dev_trace.hpp: bit 0 work counters,
+// bit 1 Cube / CSG, bit 2 KD-tree meshes, bit 3 textures / environment): scenes only pay for the code they can reach.
 //
-//   k_primary      camera ray through integer (x, y) + closest hit          (MODE_PRIMARY_ID)
-//   k_whitted      raytrace() per pixel, samples looped in order             (MODE_RENDER, gi off)
+//   k_primary      camera ray through integer (x, y) + closest hit                                  (MODE_PRIMARY_ID)
+//   k_whitted      raytrace() per pixel for scenes with recursive shaders, samples looped in order   (MODE_RENDER, gi off)
 //                  -- both as persistent waves claiming 8x8 pixel tiles (claim_items)
+//   k_wh_shade     Whitted as a wavefront (scenes without recursive shaders): camera ray(s), closest hit, Lambert / Phong::shade up to visible()
+//   k_wh_visible   visible() for every queued light-sample segment
+//   k_wh_gather    per camera sample: base + sum over lights of the visible samples' terms, the reference's FP32 order
 //   k_seed         x[397] of the mt19937 seeding recurrence per (pixel, sample)
 //   k_pt_init      path-tracing batch: generator cursors, pixel jitter, camera rays -> dense path queue
-//   k_pt_bounce    one pathtrace() iteration for every live path: closest hit, bump, discarded
-//                  spawn, next-event sample (-> shadow queue), real spawn; survivors go to the wave's
-//                  own segment of the next queue (ballot rank, no global counter)
+//   k_pt_bounce    one pathtrace() iteration for every live path: closest hit, bump, discarded spawn, next-event sample (written to the
+//                  wave's segment of the shadow queue where it is made), real spawn; survivors go to the wave's own segment of the next
+//                  path queue (ballot rank, no global counter)
 //   k_scan         per-wave survivor counts -> segment offsets (path queue and shadow queue)
-//   k_pt_shadow    visible() for every queued next-event segment, radiance added to its sample
+//   k_pt_shadow    visible() for every queued next-event segment: the sample's radiance term of this bounce
+//   k_pt_fold      a sample's radiance from its terms, innermost first
 //   k_pt_resolve   per pixel, samples summed in sample order (the reference's FP32 order)
-//   k_pack         bucket-major <-> row-major copies for the multi-GPU gather
+//   k_pack         bucket-major <-> row-major copies for the multi-GPU gather (dev_pack.hpp)
 #pragma once
 #include "dev_shade.hpp"
 #include "dev_whitted.hpp"
@@ -25,7 +30,7 @@
 #define FRAY_WHITTED_WAVES 3   // measured with persistent waves (boxed / forest DOF16 / zaphod ms): 2 -> 16.7 / 28.9 / 0.34, 3 -> 15.2 / 26.1 / 0.35, 4 -> 15.0 / 26.3 / 0.42, 5 -> 15.4 / 26.2 / 0.53
 #endif
 #ifndef FRAY_WH_SHADE_WAVES
-#define FRAY_WH_SHADE_WAVES 4   // the wavefront's closest-hit + shading kernel: 128 VGPRs, 50 spilled; forest DOF 16 24.1 -> 20.5 ms against 3 waves (168 VGPRs, 2 spilled)
+#define FRAY_WH_SHADE_WAVES 4   // the wavefront's closest-hit + shading kernel: 128 VGPRs, 9 spilled; forest DOF 16 24.1 -> 20.5 ms against 3 waves (168 VGPRs)
 #endif
 #ifndef FRAY_SHADOW_WAVES
 #define FRAY_SHADOW_WAVES 5     // the any-hit kernels at 96 VGPRs (13 / 8 spilled): boxed Whitted 12.0 -> 11.3 ms, headline -1 % against 4 waves
@@ -34,7 +39,7 @@
 #define FRAY_BOUNCE_WAVES 4   // waves per SIMD the bounce kernel is register-allocated for: 128 VGPRs, 2 spilled (3 waves: 129 VGPRs; headline 123.5 vs 116.2 ms)
 #endif
 #ifndef FRAY_BOUNCE_WAVES_NOKD
-#define FRAY_BOUNCE_WAVES_NOKD 5   // the variants without the KD walk need 106 VGPRs: 5 waves/SIMD at 96 with 7 spilled (headline 111.8 -> 108.7 ms against 4 waves)
+#define FRAY_BOUNCE_WAVES_NOKD 5   // the variants without the KD walk need 100-106 VGPRs: 5 waves/SIMD at 94-96, 0-7 spilled (headline 111.8 -> 108.7 ms against 4 waves)
 #endif
 
 // ---- kernel arguments, read where they are used ------------------------------------------------------------
@@ -42,7 +47,7 @@
 // arrays: ~150 scalar registers) end up spilled to VGPR lanes and cost a v_readlane -- a vector-ALU slot -- at every use.  These kernels
 // therefore take ONE struct and read its fields through the kernarg segment (scalar loads, served by the scalar cache) inside the loop:
 // kernel_args() returns the segment's address as a value the compiler cannot see through, once per iteration, so that nothing read
-// through it is hoisted back out of the loop.  k_pt_bounce: 147 -> 13 spilled SGPRs, headline frame 125.4 -> 122.6 ms.
+// through it is hoisted back out of the loop.  k_pt_bounce: 147 -> 13 spilled SGPRs, headline frame 125.4 -> 122.2 ms.
 template <class A> FD const FRAY_RO A* kernel_args()
 {
     const FRAY_RO A* p = (const FRAY_RO A*)__builtin_amdgcn_kernarg_segment_ptr();

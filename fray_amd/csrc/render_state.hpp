@@ -1,6 +1,6 @@
 // Host-side state behind a frayhip_scene handle and the helpers shared by the translation units of
 // the library: capi.hip (scene upload, C entry points) and render_variant.hip (render_impl<ST>, compiled
-// once per kernel flag word so the four variants build in parallel).
+// once per kernel flag word so the eight variants build in parallel).
 #pragma once
 #include <hip/hip_runtime.h>
 

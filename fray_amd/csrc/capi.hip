@@ -367,6 +367,8 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         DMesh& M = meshes[mi];
         put3(M.bmin, m.bbox_min);
         put3(M.bmax, m.bbox_max);
+        M.boxMax = 0;
+        for (int k = 0; k < 3; k++) M.boxMax = std::max(M.boxMax, std::max(std::fabs(m.bbox_min[k]), std::fabs(m.bbox_max[k])));
         M.nTris = m.n_triangles;
         M.hasKd = m.has_kd;
         if (m.has_kd) sc->kdMeshes = true;
@@ -398,8 +400,8 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
             put3(a.dNdx, T.dNdx);
             put3(a.dNdy, T.dNdy);
         }
-        // KD nodes: add each node's own box extent along its split axis.  Boxes are derived
-        // top-down exactly as BBox::split does (copy parent, overwrite one coordinate).
+        // KD nodes: add each node's own box.  Boxes are derived top-down exactly as BBox::split
+        // does (copy parent, overwrite one coordinate).
         std::vector<DKd> kd(m.n_kdnodes);
         if (m.n_kdnodes > 0) {
             struct B { double lo[3], hi[3]; };
@@ -409,12 +411,16 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
                 const frayhip_kdnode& K = m.kdnodes[n];
                 DKd& o = kd[n];
                 o.split = K.split; o.child0 = K.child0; o.parent = K.parent; o.meta = K.axis;
-                o.triBegin = K.tri_begin; o.triCount = K.tri_count; o.pad = 0;
-                o.lo = o.hi = 0;
+                o.triBegin = K.tri_begin; o.triCount = K.tri_count; o.pad[0] = o.pad[1] = 0;
+                o.up = 0; o.psplit = 0;
+                if (K.parent >= 0) {
+                    const frayhip_kdnode& U = m.kdnodes[K.parent];
+                    o.up = U.axis | ((n - U.child0) << 2);
+                    o.psplit = U.split;
+                }
+                for (int k = 0; k < 3; k++) { o.lo[k] = boxes[n].lo[k]; o.hi[k] = boxes[n].hi[k]; }
                 if (K.axis != 3) {
                     o.meta |= (m.kdnodes[K.child0].axis == 3 ? 4 : 0) | (m.kdnodes[K.child0 + 1].axis == 3 ? 8 : 0);
-                    o.lo = boxes[n].lo[K.axis];
-                    o.hi = boxes[n].hi[K.axis];
                     boxes[K.child0] = boxes[n];
                     boxes[K.child0 + 1] = boxes[n];
                     boxes[K.child0].hi[K.axis] = K.split;
@@ -501,12 +507,13 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     if (!meshes.empty()) memcpy(A.host.data() + oMeshes, meshes.data(), meshes.size() * sizeof(DMesh));
     for (int i = 0; i < d.n_nodes; i++) {
         DNode& N = nodes[i];
-        N.tlTris = 0; N.tlCulling = 0; N.pad = 0; N.tlPtr = nullptr;
+        N.tlTris = 0; N.tlCulling = 0; N.pad = 0; N.tlPtr = nullptr; N.boxMax = 0;
         for (int k = 0; k < 3; k++) N.bmin[k] = N.bmax[k] = 0;
         if (N.geomKind == FRAYHIP_GEOM_MESH && !meshes[N.geomIndex].hasKd) {
             const DMesh& M = meshes[N.geomIndex];
             N.tlTris = M.nTris; N.tlCulling = M.culling; N.tlPtr = M.tris;
             put3(N.bmin, M.bmin); put3(N.bmax, M.bmax);
+            N.boxMax = M.boxMax;
         }
     }
     if (!nodes.empty()) memcpy(A.host.data() + oNodes, nodes.data(), nodes.size() * sizeof(DNode));

@@ -6,10 +6,10 @@
 //    read (gnormal, A, ABxAC, AC, AB: SURVEY 8(a) a9), padded to 128 B so a lane fetches it with
 //    eight aligned 16-byte loads; shading attributes (pre-gathered corner normals / uvs, dNdx,
 //    dNdy) live in a separate array touched only for the winning triangle;
-//  * KD nodes are 48-byte records {split, lo, hi, child0, parent, axis, leaf range}: lo/hi are the
-//    node's own box extent along its split axis, which is what a stackless walk needs to restore
-//    the box when it climbs (the reference recomputes child boxes by BBox::split on the way down,
-//    mesh.cpp:373-376, and gets the parent box back from its call stack);
+//  * KD nodes are 96-byte records {split, child0, axis | parent, its axis and split | leaf range | the node's own box}: a
+//    stackless walk reads the box when it climbs back to a node (the reference recomputes child
+//    boxes by BBox::split on the way down, mesh.cpp:373-376, and gets the parent box back from its
+//    call stack);
 //  * nodes / lights / shaders / textures are tiny tables indexed wave-uniformly, so they are
 //    fetched through the scalar cache.
 #pragma once
@@ -46,7 +46,8 @@ struct DNode {
     int32_t pad;
     double bmin[3], bmax[3];
     const FRAY_RO DTri* tlPtr;
-};                        // 256 B
+    double boxMax;        // max |coordinate| of bmin / bmax (margins of the certified box test, dev_boxcert.hpp)
+};                        // 264 B
 
 struct DPlane { double limit, height; };
 struct DSphere { double O[3]; double R; };
@@ -69,12 +70,18 @@ struct DTriAttr {      // 168 B, winning triangle only
     double dNdx[3], dNdy[3];
 };
 
-struct DKd {           // 48 B
+struct alignas(16) DKd {   // 96 B
     double split;      // } the 16 bytes a descending step reads
     int32_t child0;    // }
     int32_t meta;      // } axis (bits 0-1; 3 = leaf) | inner: bit 2+c set = child c is a leaf
-    double lo, hi;     // the node's own box extent along its split axis (read when climbing back to it)
-    int32_t parent, triBegin, triCount, pad;
+    int32_t parent;    // } the 16 bytes a climbing step reads: the parent, its axis (bits 0-1 of `up`) and split position, and
+    int32_t up;        // } which of its children this node is (bit 2 of `up`) -- enough to tell whether the parent still has its
+    double psplit;     // } second option to try, without touching the parent's record
+    int32_t triBegin, triCount, pad[2];
+    // the node's own box, exactly the coordinates BBox::split hands down (bbox.h:205-211).  A walking lane carries the ray's
+    // parameter interval against the current box (dev_boxcert.hpp), not the box: the coordinates are read when it climbs back to
+    // a node, when a leaf's hit has to pass inside(), and when a child test has to run the reference's own arithmetic.
+    double lo[3], hi[3];
 };
 
 struct DMesh {
@@ -87,6 +94,7 @@ struct DMesh {
     // leaf's triangles are consecutive 128-byte records instead of an index list into `tris` (one dependent load less per triangle)
     const FRAY_RO DTri* ltris;
     int32_t nTris, hasKd, smooth, culling, hasUV, pad;
+    double boxMax;     // max |coordinate| of the bounding box (margins of the certified box test, dev_boxcert.hpp)
 };
 
 struct DTexture {

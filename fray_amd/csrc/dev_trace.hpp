@@ -4,14 +4,18 @@
 // Mesh::intersect with its KD-tree (mesh.cpp:144-165, 357-394).
 //
 // The KD walk is stackless: the reference recurses (depth reaches 65 on teapot_hires) and carries
-// the child boxes on its call stack.  Here a lane keeps the current box in registers, narrows one
-// coordinate when it goes down and restores it from the parent's {lo, hi} when it climbs; "which
-// child next" is recomputed from ray.start[axis] < split, so the visiting order, the set of box
-// tests, the triangles tested and the first accepted leaf are exactly the reference's.
+// the child boxes on its call stack.  Here a lane carries the ray's parameter interval against the
+// current box ({t0, n2, t1}, dev_boxcert.hpp) instead of the box: a child's interval follows from its
+// parent's with one multiplication, and it decides BBox::testIntersect for the child outright except
+// within margins of an edge, where the lane reads the node's box and runs the reference's arithmetic.
+// "Which child next" is recomputed from ray.start[axis] < split, so the visiting order, the outcome of
+// every box test, the triangles tested and the first accepted leaf are exactly the reference's.
 #pragma once
 #include "dev_math.hpp"
 #include "dev_scene.hpp"
 #include "dev_sort.hpp"
+#define FRAY_CERT_SEQ() __builtin_amdgcn_sched_barrier(0)
+#include "dev_boxcert.hpp"
 
 // Per-lane work counters (frayhip_stats); only the <true> instantiations touch them.
 struct Cnt {
@@ -43,7 +47,8 @@ struct Box6 { double lox, loy, loz, hix, hiy, hiz; };
 
 // Local ray of a node (Transform::untransformPoint / untransformDir, matrix.cpp:148-161), cached per
 // transform class: nodes whose {offset, invM} are bitwise identical yield the same local ray.
-struct LocalRay { V3 s, d, rd; int cls; bool haveRd; };
+// rmax / sMax / dirOk: what the certified box test's margins are made of (cert_ray, dev_boxcert.hpp), functions of the local ray too.
+struct LocalRay { V3 s, d, rd; int cls; bool haveRd, dirOk; double rmax, sMax; };
 
 
 FD bool box_inside(const Box6& b, V3 v)   // BBox::inside, bbox.h:79-84
@@ -156,22 +161,89 @@ FD void tri_bary(const FRAY_RO DTri* T, V3 s, V3 d, double& l2, double& l3)
     l3 = dot(cross(AB, H), D) * rDcr;
 }
 
+// RRay::prepareForTracing (bbox.h:49-54) of a local ray -- a function of the local ray only, computed once per transform class --
+// and the ray's part of the certified box test's margins.
+FD V3 ray_rdir(V3 d)
+{
+    V3 rd;
+    rd.x = fabs(d.x) > 1e-12 ? 1.0 / d.x : 1e12;
+    rd.y = fabs(d.y) > 1e-12 ? 1.0 / d.y : 1e12;
+    rd.z = fabs(d.z) > 1e-12 ? 1.0 / d.z : 1e12;
+    return rd;
+}
+FD void prepare_ray(LocalRay& lr)
+{
+    if (lr.haveRd) return;
+    lr.rd = ray_rdir(lr.d);
+    lr.rmax = __builtin_fmax(__builtin_fmax(fabs(lr.rd.x), fabs(lr.rd.y)), fabs(lr.rd.z));
+    lr.sMax = __builtin_fmax(__builtin_fmax(fabs(lr.s.x), fabs(lr.s.y)), fabs(lr.s.z));
+    lr.dirOk = __builtin_fmin(__builtin_fmin(fabs(lr.d.x), fabs(lr.d.y)), fabs(lr.d.z)) >= 1e-6;
+    lr.haveRd = true;
+}
+
+// BBox::testIntersect, certified (dev_boxcert.hpp): decided from the ray's parameter interval against the box; the reference's
+// arithmetic (box_test) runs only for the lanes the interval cannot decide.  `st` is the interval, for the walk below a root.
+FD bool box_test_cert(const Box6& b, const LocalRay& lr, const CertRay& cr, TState& st)
+{
+    st = tstate_box(b.lox, b.loy, b.loz, b.hix, b.hiy, b.hiz, lr.s.x, lr.s.y, lr.s.z, lr.rd.x, lr.rd.y, lr.rd.z);
+    const int cls = cert_classify(st, cr);
+    bool res = cls > 0;
+#ifndef FRAY_EXP_NOEXACT
+    if (cls < 0) res = box_test(b, lr.s, lr.d, lr.rd);
+#endif
+    return res;
+}
+
+FD Box6 kd_box(const FRAY_RO DKd* n)
+{
+    Box6 b;
+    b.lox = n->lo[0]; b.loy = n->lo[1]; b.loz = n->lo[2];
+    b.hix = n->hi[0]; b.hiy = n->hi[1]; b.hiz = n->hi[2];
+    return b;
+}
+
+// Position of a lane in the stackless KD walk: "(P, k): about to test child option k of inner node P" (k = 0: the near child,
+// picked by ray.start[axis] < split; k = 1: the other one), P's header and the ray's interval against P's box.
+struct KdPos {
+    int P, k, child0, axis, leafMask;
+    double split;
+    TState st;
+};
+// Both children of the subtree rooted at `nd` are done (or `nd` is a finished leaf): go up until a parent still has its second child to
+// try.  A climbing step reads 16 bytes of the node it leaves (parent, the parent's axis and split, which child the node is); the
+// parent's own record -- header and box, for the interval -- is read only where the climb stops.  False: back above the root.
+FD bool kd_climb(const FRAY_RO DKd* kd, int nd, const LocalRay& lr, KdPos& w)
+{
+    for (;;) {
+        const int p = kd[nd].parent, up = kd[nd].up;
+        const double ps = kd[nd].psplit;
+        if (p < 0) return false;
+        const int pa = up & 3;
+        const int pfirst = comp(lr.s, pa) < ps ? 0 : 1;
+        if ((up >> 2) == pfirst) {
+            w.P = p; w.k = 1; w.axis = pa; w.split = ps;
+            w.child0 = kd[p].child0;
+            w.leafMask = kd[p].meta >> 2;
+            const Box6 b = kd_box(kd + p);
+            w.st = tstate_box(b.lox, b.loy, b.loz, b.hix, b.hiy, b.hiz, lr.s.x, lr.s.y, lr.s.z, lr.rd.x, lr.rd.y, lr.rd.z);
+            return true;
+        }
+        nd = p;
+    }
+}
+
 // Mesh::intersect (mesh.cpp:144-165).  On true: gamma / tri / l2 / l3 describe info.
 template <int ST>
 FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int& tri, double& l2, double& l3, Cnt& c)
 {
-    const V3 s = lr.s, d = lr.d;
-    if (!lr.haveRd) {   // RRay::prepareForTracing, bbox.h:49-54 -- a function of the local ray only
-        lr.rd.x = fabs(d.x) > 1e-12 ? 1.0 / d.x : 1e12;
-        lr.rd.y = fabs(d.y) > 1e-12 ? 1.0 / d.y : 1e12;
-        lr.rd.z = fabs(d.z) > 1e-12 ? 1.0 / d.z : 1e12;
-        lr.haveRd = true;
-    }
-    const V3 rd = lr.rd;
+    prepare_ray(lr);
+    const V3 s = lr.s, d = lr.d, rd = lr.rd;
+    const CertRay cr = cert_ray(lr.rmax, lr.sMax, lr.dirOk, M.boxMax);
     Box6 box;
     box.lox = M.bmin[0]; box.loy = M.bmin[1]; box.loz = M.bmin[2];
     box.hix = M.bmax[0]; box.hiy = M.bmax[1]; box.hiz = M.bmax[2];
-    const bool rootHit = box_test(box, s, d, rd);
+    KdPos w;
+    const bool rootHit = box_test_cert(box, lr, cr, w.st);
     STAMP(2);
     if (!rootHit) return false;
     gamma = 1e99;
@@ -185,60 +257,49 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
         return found;
     }
     // ---- stackless KD walk (Mesh::intersectKD, mesh.cpp:357-394) ----
-    // A lane's position is "(P, k): about to test child option k of inner node P, with P's box in
-    // registers" (k = 0: the near child, picked by ray.start[axis] < split; k = 1: the other one).
-    // The loop is written while-while: an inner loop whose every iteration is exactly one box test
-    // for every lane still walking, until the lane stands in a leaf (or has left the root); then
-    // the leaf's triangles; then back to walking.  Lanes of a wave therefore run box tests together
-    // and triangle tests together instead of interleaving them.  Per lane the sequence of box
-    // tests, leaves and triangles is the reference's recursion, step for step.
+    // The loop is written while-while: an inner loop whose every iteration is exactly one child test for every lane still
+    // walking, until the lane stands in a leaf (or has left the root); then the leaf's triangles; then back to walking.  Lanes
+    // of a wave therefore run child tests together and triangle tests together instead of interleaving them.  Per lane the
+    // sequence of box tests (and their outcomes), leaves and triangles is the reference's recursion, step for step.
     const FRAY_RO DKd* kd = M.kd;
-    int P = 0, k = 0;
-    int meta = kd[0].meta, child0 = kd[0].child0;
-    int axis = meta & 3, leafMask = meta >> 2;
-    double split = kd[0].split;
+    w.P = 0; w.k = 0;
+    {
+        const int meta = kd[0].meta;
+        w.child0 = kd[0].child0; w.axis = meta & 3; w.leafMask = meta >> 2; w.split = kd[0].split;
+    }
     bump<ST>(c.kdInner);
     bool alive = true;
     for (;;) {
         int leaf = -1;
-        int node = 0;                  // the node whose options are exhausted (climb start)
         while (alive && leaf < 0) {
-            const int first = comp(s, axis) < split ? 0 : 1;
-            const int ch = k == 0 ? first : 1 - first;
-            Box6 cb = box;                                // BBox::split, bbox.h:205-211
-            if (ch == 0) box_set_hi(cb, axis, split); else box_set_lo(cb, axis, split);
-            bool climb = false;
-            if (box_test(cb, s, d, rd)) {
-                box = cb;
-                const int child = child0 + ch;
-                if ((leafMask >> ch) & 1) {
+            // the split plane's parameter (the reference's own expression for the plane, bbox.h:97) and the child's interval
+            const double diff = w.split - comp(s, w.axis);
+            const double ra = comp(rd, w.axis);
+            const int first = diff > 0 ? 0 : 1;                     // ray.start[axis] < splitPos, mesh.cpp:381
+            const int ch = w.k == 0 ? first : 1 - first;
+            const TState cs = tstate_child(w.st, diff * ra, (ch == 0) == (ra > 0));
+            const int cls = cert_classify(cs, cr);
+            bool hit = cls > 0;
+            if (cls < 0) {                                          // within margins of an edge: BBox::split + testIntersect as the reference computes them
+                Box6 cb = kd_box(kd + w.P);
+                if (ch == 0) box_set_hi(cb, w.axis, w.split); else box_set_lo(cb, w.axis, w.split);
+                hit = box_test(cb, s, d, rd);
+            }
+            if (hit) {
+                const int child = w.child0 + ch;
+                if ((w.leafMask >> ch) & 1) {
                     leaf = child;
                 } else {
-                    P = child; k = 0;
-                    meta = kd[P].meta; child0 = kd[P].child0; split = kd[P].split;
-                    axis = meta & 3; leafMask = meta >> 2;
+                    w.P = child; w.k = 0; w.st = cs;
+                    const int meta = kd[child].meta;
+                    w.child0 = kd[child].child0; w.split = kd[child].split;
+                    w.axis = meta & 3; w.leafMask = meta >> 2;
                     bump<ST>(c.kdInner);
                 }
-            } else if (k == 0) {
-                k = 1;
+            } else if (w.k == 0) {
+                w.k = 1;
             } else {
-                climb = true;
-                node = P;
-            }
-            if (climb) {
-                // both children of P are done: go up until a parent still has its second child to try
-                for (;;) {
-                    const int p = kd[node].parent;
-                    if (p < 0) { alive = false; break; }          // back above the root: no leaf accepted
-                    const int pm = kd[p].meta, pa = pm & 3;
-                    const double ps = kd[p].split;
-                    const int pc = kd[p].child0;
-                    box_set_lo(box, pa, kd[p].lo);                  // the parent's box again
-                    box_set_hi(box, pa, kd[p].hi);
-                    const int pfirst = comp(s, pa) < ps ? 0 : 1;
-                    if (node - pc == pfirst) { P = p; k = 1; axis = pa; split = ps; child0 = pc; leafMask = pm >> 2; break; }
-                    node = p;
-                }
+                alive = kd_climb(kd, w.P, lr, w);
             }
         }
         if (!alive) return false;
@@ -251,25 +312,11 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
                 bump<ST>(c.leafRefs);
                 if (tri_test<ST>(lt + t, culling, s, d, gamma, l2, l3, c)) { found = true; tri = lt[t].index; }
             }
-            if (found && box_inside(box, s + d * gamma)) return true;
+            if (found && box_inside(kd_box(kd + leaf), s + d * gamma)) return true;
         }
-        // the leaf is done: continue with its parent's remaining option (the box is restored while climbing)
-        {
-            int nd = leaf;
-            for (;;) {
-                const int p = kd[nd].parent;
-                if (p < 0) { alive = false; break; }
-                const int pm = kd[p].meta, pa = pm & 3;
-                const double ps = kd[p].split;
-                const int pc = kd[p].child0;
-                box_set_lo(box, pa, kd[p].lo);
-                box_set_hi(box, pa, kd[p].hi);
-                const int pfirst = comp(s, pa) < ps ? 0 : 1;
-                if (nd - pc == pfirst) { P = p; k = 1; axis = pa; split = ps; child0 = pc; leafMask = pm >> 2; break; }
-                nd = p;
-            }
-            if (!alive) return false;
-        }
+        // the leaf is done: continue with its parent's remaining option
+        alive = kd_climb(kd, leaf, lr, w);
+        if (!alive) return false;
     }
 }
 
@@ -342,7 +389,7 @@ FD bool prim_intersect(const DScene& S, int kind, int index, V3 s, V3 d, V3 rd, 
     }
     // mesh
     LocalRay lr;
-    lr.s = s; lr.d = d; lr.rd = rd; lr.cls = 0; lr.haveRd = true;
+    lr.s = s; lr.d = d; lr.cls = 0; lr.haveRd = false;
     double gamma;
     int tri = -1;
     double l2 = 0, l3 = 0;
@@ -432,16 +479,6 @@ FD bool csg_intersect(const DScene& S, const FRAY_RO DCsg& G, V3 s, V3 d, V3 rd,
     return false;
 }
 
-// RRay::prepareForTracing (bbox.h:49-54) of a local ray, for the meshes below a CSG node
-FD V3 ray_rdir(V3 d)
-{
-    V3 rd;
-    rd.x = fabs(d.x) > 1e-12 ? 1.0 / d.x : 1e12;
-    rd.y = fabs(d.y) > 1e-12 ? 1.0 / d.y : 1e12;
-    rd.z = fabs(d.z) > 1e-12 ? 1.0 / d.z : 1e12;
-    return rd;
-}
-
 // Geometry part of Node::intersect for node N on the local ray; on a hit returns the local
 // intersection point and fills t / tri / l2 / l3.
 template <int ST>
@@ -506,11 +543,12 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, LocalRay& lr, V3
     // mesh
     double gamma;
     if (N.tlTris > 0) {      // no KD-tree: Mesh::intersect's brute-force loop (mesh.cpp:146-161) on the node's own copy of the mesh header
-        if (!lr.haveRd) { lr.rd = ray_rdir(ld); lr.haveRd = true; }
+        prepare_ray(lr);
         Box6 box;
         box.lox = N.bmin[0]; box.loy = N.bmin[1]; box.loz = N.bmin[2];
         box.hix = N.bmax[0]; box.hiy = N.bmax[1]; box.hiz = N.bmax[2];
-        const bool rootHit = box_test(box, ls, ld, lr.rd);
+        TState st;
+        const bool rootHit = box_test_cert(box, lr, cert_ray(lr.rmax, lr.sMax, lr.dirOk, N.boxMax), st);
         STAMP(2);
         if (!rootHit) return false;
         gamma = 1e99;

@@ -28,7 +28,7 @@ fray_amd/csrc/%.o: fray_amd/csrc/%.cpp $(HIP_HDR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
 fray_amd/csrc/%.o: fray_amd/csrc/%.hip $(HIP_HDR)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -c $< -o $@
 
 # -Rpass-analysis=kernel-resource-usage: registers, spills, scratch and LDS of every kernel of the variant (kept
 # next to the object; `make resources` gathers them into profiles/)

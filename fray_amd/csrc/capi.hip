@@ -253,9 +253,12 @@ std::string validate_desc(const frayhip_scene_desc& d)
         }
         if (m.has_kd) {
             if (m.n_kdnodes <= 0) return bad("has_kd without nodes in mesh", i);
+            std::vector<int> depth((size_t)m.n_kdnodes, 0);
             for (int k = 0; k < m.n_kdnodes; k++) {
                 const frayhip_kdnode& n = m.kdnodes[k];
                 if (n.parent < -1 || n.parent >= k || (k == 0) != (n.parent == -1)) return bad("KD parent link is not a tree in mesh", i);
+                // the walk's stack of pending children holds one entry per level (dev_trace.hpp); the reference's builder stops at 65 (constants.h:39)
+                if (k > 0 && (depth[k] = depth[n.parent] + 1) >= FRAY_KD_MAX_DEPTH) return bad("KD tree deeper than the walk's stack (72 levels) in mesh", i);
                 if (n.axis == 3) {
                     if (n.tri_begin < 0 || n.tri_count < 0 || (int64_t)n.tri_begin + n.tri_count > m.n_trirefs) return bad("KD leaf range out of bounds in mesh", i);
                 } else if (n.axis >= 0 && n.axis <= 2) {

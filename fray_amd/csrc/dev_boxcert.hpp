@@ -102,10 +102,18 @@ FRAY_CERT_FN TState tstate_child(TState p, double ts, bool farPlane)
     return c;
 }
 
+// yes: surely true; unc: neither surely true nor surely false
+FRAY_CERT_FN void cert_decide(TState t, CertRay c, bool& yes, bool& unc)
+{
+    const bool y = (t.t0 >= c.mu && t.n2 + c.mu <= t.t0 && t.t0 + c.mu <= t.t1) || (t.t0 <= -c.mu && t.t1 >= c.mu);
+    const bool n = (t.t0 > t.t1 + 3.0 * c.mu && t.t0 > c.A) || (t.t1 < -c.A);
+    yes = y && c.ok;
+    unc = !c.ok || !(y || n);
+}
 // +1 surely true, 0 surely false, -1 uncertain
 FRAY_CERT_FN int cert_classify(TState t, CertRay c)
 {
-    const bool yes = (t.t0 >= c.mu && t.n2 + c.mu <= t.t0 && t.t0 + c.mu <= t.t1) || (t.t0 <= -c.mu && t.t1 >= c.mu);
-    const bool no = (t.t0 > t.t1 + 3.0 * c.mu && t.t0 > c.A) || (t.t1 < -c.A);
-    return !c.ok ? -1 : (yes ? 1 : (no ? 0 : -1));
+    bool yes, unc;
+    cert_decide(t, c, yes, unc);
+    return unc ? -1 : (yes ? 1 : 0);
 }

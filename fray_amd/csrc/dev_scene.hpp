@@ -31,6 +31,11 @@
 #define FRAY_CSG_DEPTH 8  // CsgOp levels the device unrolls: 1 = operands are plain geometries; deeper scenes are rejected at upload
 #endif
 
+// The KD walk's stack of pending children (dev_trace.hpp): the 16 most recent entries of a lane in LDS, older ones in scratch; deeper trees are
+// rejected at upload (the reference's builder stops at depth 65, constants.h:39).
+#define FRAY_KD_LDS_STACK 16
+#define FRAY_KD_MAX_DEPTH 72
+
 struct DXform { double off[3]; double m[9]; double inv[9]; };
 
 struct DTri;

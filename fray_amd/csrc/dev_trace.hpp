@@ -186,11 +186,9 @@ FD void prepare_ray(LocalRay& lr)
 FD bool box_test_cert(const Box6& b, const LocalRay& lr, const CertRay& cr, TState& st)
 {
     st = tstate_box(b.lox, b.loy, b.loz, b.hix, b.hiy, b.hiz, lr.s.x, lr.s.y, lr.s.z, lr.rd.x, lr.rd.y, lr.rd.z);
-    const int cls = cert_classify(st, cr);
-    bool res = cls > 0;
-#ifndef FRAY_EXP_NOEXACT
-    if (cls < 0) res = box_test(b, lr.s, lr.d, lr.rd);
-#endif
+    bool res, unc;
+    cert_decide(st, cr, res, unc);
+    if (unc) res = box_test(b, lr.s, lr.d, lr.rd);
     return res;
 }
 
@@ -202,34 +200,35 @@ FD Box6 kd_box(const FRAY_RO DKd* n)
     return b;
 }
 
-// Position of a lane in the stackless KD walk: "(P, k): about to test child option k of inner node P" (k = 0: the near child,
-// picked by ray.start[axis] < split; k = 1: the other one), P's header and the ray's interval against P's box.
-struct KdPos {
-    int P, k, child0, axis, leafMask;
-    double split;
-    TState st;
+// The walk's stack of pending far children (node index; bit 31 = the node is a leaf).  The reference's recursion returns to a
+// parent to try its second child (mesh.cpp:386-391); both children's box tests are pure functions of the ray, so they are evaluated
+// together when the parent is entered and a far child that passed waits here until the near subtree is done without an accepted
+// hit.  The 16 most recent entries of a lane live in LDS (stride 256 words: a lane always hits bank lane % 32, no conflicts),
+// older ones in the lane's scratch memory: a tree is at most FRAY_KD_MAX_DEPTH levels deep (frayhip_scene_create checks; the
+// reference's builder stops at 65, constants.h:39), so at most that many children are ever pending.
+struct KdStack {
+    int sp, lo;                                      // entries [lo, sp) are in LDS, [0, lo) in scratch
+    int spill[FRAY_KD_MAX_DEPTH - FRAY_KD_LDS_STACK];
 };
-// Both children of the subtree rooted at `nd` are done (or `nd` is a finished leaf): go up until a parent still has its second child to
-// try.  A climbing step reads 16 bytes of the node it leaves (parent, the parent's axis and split, which child the node is); the
-// parent's own record -- header and box, for the interval -- is read only where the climb stops.  False: back above the root.
-FD bool kd_climb(const FRAY_RO DKd* kd, int nd, const LocalRay& lr, KdPos& w)
+FD int* kd_stack_slot(int i)
 {
-    for (;;) {
-        const int p = kd[nd].parent, up = kd[nd].up;
-        const double ps = kd[nd].psplit;
-        if (p < 0) return false;
-        const int pa = up & 3;
-        const int pfirst = comp(lr.s, pa) < ps ? 0 : 1;
-        if ((up >> 2) == pfirst) {
-            w.P = p; w.k = 1; w.axis = pa; w.split = ps;
-            w.child0 = kd[p].child0;
-            w.leafMask = kd[p].meta >> 2;
-            const Box6 b = kd_box(kd + p);
-            w.st = tstate_box(b.lox, b.loy, b.loz, b.hix, b.hiy, b.hiz, lr.s.x, lr.s.y, lr.s.z, lr.rd.x, lr.rd.y, lr.rd.z);
-            return true;
-        }
-        nd = p;
+    __shared__ int slots[FRAY_KD_LDS_STACK][256];
+    return &slots[i & (FRAY_KD_LDS_STACK - 1)][threadIdx.x];
+}
+FD void kd_push(KdStack& k, int e)
+{
+    if (k.sp - k.lo == FRAY_KD_LDS_STACK) {          // the oldest LDS entry makes room
+        k.spill[k.lo] = *kd_stack_slot(k.lo);
+        k.lo++;
     }
+    *kd_stack_slot(k.sp) = e;
+    k.sp++;
+}
+FD int kd_pop(KdStack& k)                            // caller checked sp > 0
+{
+    k.sp--;
+    if (k.sp < k.lo) { k.lo = k.sp; return k.spill[k.sp]; }
+    return *kd_stack_slot(k.sp);
 }
 
 // Mesh::intersect (mesh.cpp:144-165).  On true: gamma / tri / l2 / l3 describe info.
@@ -242,8 +241,8 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
     Box6 box;
     box.lox = M.bmin[0]; box.loy = M.bmin[1]; box.loz = M.bmin[2];
     box.hix = M.bmax[0]; box.hiy = M.bmax[1]; box.hiz = M.bmax[2];
-    KdPos w;
-    const bool rootHit = box_test_cert(box, lr, cr, w.st);
+    TState st;                                       // the ray's interval against the current node's box
+    const bool rootHit = box_test_cert(box, lr, cr, st);
     STAMP(2);
     if (!rootHit) return false;
     gamma = 1e99;
@@ -256,51 +255,72 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
         STAMP(3);
         return found;
     }
-    // ---- stackless KD walk (Mesh::intersectKD, mesh.cpp:357-394) ----
-    // The loop is written while-while: an inner loop whose every iteration is exactly one child test for every lane still
-    // walking, until the lane stands in a leaf (or has left the root); then the leaf's triangles; then back to walking.  Lanes
-    // of a wave therefore run child tests together and triangle tests together instead of interleaving them.  Per lane the
-    // sequence of box tests (and their outcomes), leaves and triangles is the reference's recursion, step for step.
+    // ---- KD walk (Mesh::intersectKD, mesh.cpp:357-394) ----
+    // while-while: an inner loop whose every iteration handles ONE inner node for every lane still walking (both child tests, then
+    // down into the near child, or the far one, or on to the most recent pending far child), until the lane stands in a leaf or has
+    // nothing pending; then the leaf's triangles; then back to walking.  Lanes of a wave therefore run child tests together and
+    // triangle tests together.  Per lane the outcomes of the box tests, the order of inner nodes, leaves and triangles, and the first
+    // accepted leaf are the reference's recursion, step for step.
     const FRAY_RO DKd* kd = M.kd;
-    w.P = 0; w.k = 0;
-    {
-        const int meta = kd[0].meta;
-        w.child0 = kd[0].child0; w.axis = meta & 3; w.leafMask = meta >> 2; w.split = kd[0].split;
-    }
-    bump<ST>(c.kdInner);
+    KdStack stk;
+    stk.sp = 0; stk.lo = 0;
+    int P = 0;                                       // the inner node being entered
+    int leaf = -1;                                   // >= 0: the lane stands in this leaf
     bool alive = true;
     for (;;) {
-        int leaf = -1;
         while (alive && leaf < 0) {
-            // the split plane's parameter (the reference's own expression for the plane, bbox.h:97) and the child's interval
-            const double diff = w.split - comp(s, w.axis);
-            const double ra = comp(rd, w.axis);
-            const int first = diff > 0 ? 0 : 1;                     // ray.start[axis] < splitPos, mesh.cpp:381
-            const int ch = w.k == 0 ? first : 1 - first;
-            const TState cs = tstate_child(w.st, diff * ra, (ch == 0) == (ra > 0));
-            const int cls = cert_classify(cs, cr);
-            bool hit = cls > 0;
-            if (cls < 0) {                                          // within margins of an edge: BBox::split + testIntersect as the reference computes them
-                Box6 cb = kd_box(kd + w.P);
-                if (ch == 0) box_set_hi(cb, w.axis, w.split); else box_set_lo(cb, w.axis, w.split);
-                hit = box_test(cb, s, d, rd);
-            }
-            if (hit) {
-                const int child = w.child0 + ch;
-                if ((w.leafMask >> ch) & 1) {
-                    leaf = child;
-                } else {
-                    w.P = child; w.k = 0; w.st = cs;
-                    const int meta = kd[child].meta;
-                    w.child0 = kd[child].child0; w.split = kd[child].split;
-                    w.axis = meta & 3; w.leafMask = meta >> 2;
-                    bump<ST>(c.kdInner);
+            bump<ST>(c.kdInner);
+            const double split = kd[P].split;
+            const int child0 = kd[P].child0, meta = kd[P].meta;
+            const int axis = meta & 3;
+            // the split plane's parameter (the reference's own expression for the plane, bbox.h:97) and the children's intervals:
+            // one child takes the plane as its far plane, the other as its near plane
+            const double diff = split - comp(s, axis);
+            const double ra = comp(rd, axis);
+            const double ts = diff * ra;
+            const int nearCh = diff > 0 ? 0 : 1;                    // ray.start[axis] < splitPos, mesh.cpp:381: visited first
+            const bool nearTakesFar = (nearCh == 0) == (ra > 0);    // the first child has the split plane as its FAR plane
+            const TState sa = tstate_child(st, ts, true), sb = tstate_child(st, ts, false);
+            bool yA, uA, yB, uB;
+            cert_decide(sa, cr, yA, uA);
+            cert_decide(sb, cr, yB, uB);
+            bool hitNear = nearTakesFar ? yA : yB, hitFar = nearTakesFar ? yB : yA;
+            const bool uncNear = nearTakesFar ? uA : uB, uncFar = nearTakesFar ? uB : uA;
+            if (uncNear || uncFar) {                                // within margins of an edge: BBox::split + testIntersect as the reference computes them
+                const Box6 pb = kd_box(kd + P);
+                if (uncNear) {
+                    Box6 cb = pb;
+                    if (nearCh == 0) box_set_hi(cb, axis, split); else box_set_lo(cb, axis, split);
+                    hitNear = box_test(cb, s, d, rd);
                 }
-            } else if (w.k == 0) {
-                w.k = 1;
-            } else {
-                alive = kd_climb(kd, w.P, lr, w);
+                if (uncFar) {
+                    Box6 cb = pb;
+                    if (nearCh == 1) box_set_hi(cb, axis, split); else box_set_lo(cb, axis, split);
+                    hitFar = box_test(cb, s, d, rd);
+                }
             }
+            const int farNode = child0 + 1 - nearCh, farLeaf = (meta >> (3 - nearCh)) & 1;
+            int next = -1, nextLeaf = 0;
+            if (hitNear) {
+                if (hitFar) kd_push(stk, farNode | (farLeaf << 31));
+                next = child0 + nearCh; nextLeaf = (meta >> (2 + nearCh)) & 1;
+                st = nearTakesFar ? sa : sb;
+            } else if (hitFar) {
+                next = farNode; nextLeaf = farLeaf;
+                st = nearTakesFar ? sb : sa;
+            }
+            STAMP(4);
+            if (next < 0) {                                         // neither child: on to the most recent pending far child
+                if (stk.sp == 0) { alive = false; break; }
+                const int e = kd_pop(stk);
+                next = e & 0x7fffffff; nextLeaf = (unsigned)e >> 31;
+                if (!nextLeaf) {
+                    const Box6 b = kd_box(kd + next);
+                    st = tstate_box(b.lox, b.loy, b.loz, b.hix, b.hiy, b.hiz, s.x, s.y, s.z, rd.x, rd.y, rd.z);
+                }
+                STAMP(9);
+            }
+            if (nextLeaf) leaf = next; else P = next;
         }
         if (!alive) return false;
         // ---- leaf: test every triangle, accept iff found && inside(leaf box, ip)
@@ -312,11 +332,23 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
                 bump<ST>(c.leafRefs);
                 if (tri_test<ST>(lt + t, culling, s, d, gamma, l2, l3, c)) { found = true; tri = lt[t].index; }
             }
+            STAMP(11);
             if (found && box_inside(kd_box(kd + leaf), s + d * gamma)) return true;
         }
-        // the leaf is done: continue with its parent's remaining option
-        alive = kd_climb(kd, leaf, lr, w);
-        if (!alive) return false;
+        // the leaf is done: on to the most recent pending far child (a pending leaf waits for the next round of triangle tests)
+        if (stk.sp == 0) return false;
+        {
+            const int e = kd_pop(stk);
+            const int next = e & 0x7fffffff;
+            if ((unsigned)e >> 31) leaf = next;
+            else {
+                leaf = -1;
+                P = next;
+                const Box6 b = kd_box(kd + next);
+                st = tstate_box(b.lox, b.loy, b.loz, b.hix, b.hiy, b.hiz, s.x, s.y, s.z, rd.x, rd.y, rd.z);
+            }
+            STAMP(9);
+        }
     }
 }
 

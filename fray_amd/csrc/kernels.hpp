@@ -190,7 +190,11 @@ static __global__ __launch_bounds__(256, kd_variant(ST) ? FRAY_PRIMARY_WAVES : F
     Cnt c = zero_cnt();
     const int nItems = A.nItems;
     DCursors* const cur = A.cur;
+#ifdef FRAY_STAMPS
+    stamp_begin();
+#endif
     for (int r = 0, item = claim_items(cur, nItems, r); item < nItems; item = claim_items(cur, nItems, r)) {
+        STAMP(0);
         const FRAY_RO PrimaryArgs* AP = kernel_args<PrimaryArgs>();
         const DScene& S = KARG(PrimaryArgs, AP, S);
         const DCamera& C = KARG(PrimaryArgs, AP, C);
@@ -206,7 +210,11 @@ static __global__ __launch_bounds__(256, kd_variant(ST) ? FRAY_PRIMARY_WAVES : F
         double* const hitDist = KARG(PrimaryArgs, AP, hitDist);
         if (hitId) hitId[p] = h.node;
         if (hitDist) hitDist[p] = h.dist;
+        STAMP(13);
     }
+#ifdef FRAY_STAMPS
+    if ((threadIdx.x & 63) < 16) atomicAdd(&A.st->stamp[threadIdx.x & 63], g_stampAcc[threadIdx.x >> 6][threadIdx.x & 63]);
+#endif
     if (ST & 1) flush_stats(A.st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&A.st->rngOverflow, 1ull);
 }
@@ -371,7 +379,11 @@ static __global__ __launch_bounds__(256, FRAY_WH_SHADE_WAVES) void k_wh_shade(Wh
     const size_t N = (size_t)total * (stereo ? 2 : 1);
     bool ovf = false;
     __shared__ double rightRay[6][256];
+#ifdef FRAY_STAMPS
+    stamp_begin();
+#endif
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += gridDim.x * blockDim.x) {
+        STAMP(13);
         const FRAY_RO WhShadeArgs* AP = kernel_args<WhShadeArgs>();
         const DScene& S = KARG(WhShadeArgs, AP, S);
         const DCamera& C = KARG(WhShadeArgs, AP, C);
@@ -415,9 +427,14 @@ static __global__ __launch_bounds__(256, FRAY_WH_SHADE_WAVES) void k_wh_shade(Wh
                 o = v3(rightRay[0][threadIdx.x], rightRay[1][threadIdx.x], rightRay[2][threadIdx.x]);
                 d = v3(rightRay[3][threadIdx.x], rightRay[4][threadIdx.x], rightRay[5][threadIdx.x]);
             }
+            STAMP(0);
             wh_shade_eye<ST>(S, o, d, tab, Q, N, (size_t)eye * total + slot, c);
+            STAMP(10);
         }
     }
+#ifdef FRAY_STAMPS
+    if ((threadIdx.x & 63) < 16) atomicAdd(&st->stamp[threadIdx.x & 63], g_stampAcc[threadIdx.x >> 6][threadIdx.x & 63]);
+#endif
     if (ovf) atomicAdd(&st->rngOverflow, 1ull);
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
@@ -431,14 +448,22 @@ static __global__ __launch_bounds__(256, kd_variant(ST) ? FRAY_SHADOW_WAVES : FR
     const size_t N = A.N;
     DStats* const st = A.st;
     const size_t total = N * (size_t)A.T;
+#ifdef FRAY_STAMPS
+    stamp_begin();
+#endif
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        STAMP(13);
         const FRAY_RO WhVisibleArgs* AP = kernel_args<WhVisibleArgs>();
         const DScene& S = KARG(WhVisibleArgs, AP, S);
         const WhittedQueue& Q = KARG(WhVisibleArgs, AP, Q);
         const size_t e = t % N;
         if (!Q.hit[e]) continue;
+        STAMP(0);
         Q.vis[t] = visible<ST>(S, v3(Q.ax[e], Q.ay[e], Q.az[e]), v3(Q.bx[t], Q.by[t], Q.bz[t]), c) ? 1 : 0;
     }
+#ifdef FRAY_STAMPS
+    if ((threadIdx.x & 63) < 16) atomicAdd(&st->stamp[threadIdx.x & 63], g_stampAcc[threadIdx.x >> 6][threadIdx.x & 63]);
+#endif
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }

@@ -291,13 +291,13 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     HIP_TRY(hipMemcpy(dsv, sc->d_stats, sizeof dsv, hipMemcpyDeviceToHost));
 #ifdef FRAY_STAMPS
     {
-        static const char* names[16] = {"queue lookup + ray load", "local ray (transform)", "root box test", "tree-less triangle loop", "-", "other geometry (plane/sphere/KD)",
-                                        "phase B: results + merge", "lights", "load rest of path", "-", "shading (finalize .. spawn)", "-",
-                                        "phase A: store to LDS", "phase C / queue stores", "phase B: list build", "phase B: gather + local ray"};
+        static const char* names[16] = {"queue lookup + ray load / camera ray", "local ray (transform)", "root box test", "tree-less triangle loop", "KD walk: child tests", "other geometry (plane / sphere / KD leaf accept)",
+                                        "node result + world distance", "lights", "load rest of path", "KD walk: climbs", "shading (finalize .. spawn / light loops)", "KD leaves: triangle tests",
+                                        "-", "queue stores / loop overhead", "-", "-"};
         for (int q = 0; q < 2; q++) {
             double tot = 0;
             for (int k = 0; k < 16; k++) tot += (double)dsv[q].stamp[k];
-            fprintf(stderr, "[stamps] %s: total %.4g wave-cycles\n", q == 0 ? "k_pt_bounce (+ other kernels on this DStats)" : "k_pt_shadow", tot);
+            fprintf(stderr, "[stamps] %s: total %.4g wave-cycles\n", q == 0 ? "closest-hit kernel (k_pt_bounce / k_primary / k_wh_shade)" : "any-hit kernel (k_pt_shadow / k_wh_visible)", tot);
             for (int k = 0; k < 16; k++) if (dsv[q].stamp[k]) fprintf(stderr, "[stamps]   %-36s %6.2f %%\n", names[k], 100.0 * (double)dsv[q].stamp[k] / tot);
         }
     }

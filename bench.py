@@ -166,6 +166,7 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--spp-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-serial-pass", action="store_true", help="skip the serialised pass that times every launch alone (path tracing): durations then come from the timed region")
     ap.add_argument("--check", action="store_true", help="N > 1: also render the whole frame on rank 0 and require the gathered frame to equal it")
     ap.add_argument("--torch-gather", action="store_true", help="N > 1: exchange through torch.distributed.gather instead of frayhip_gather_buckets")
     ap.add_argument("--shard-of", type=int, default=0, help="diagnosis on one GPU: render only rank 0's share of an N-rank run (buckets 0 mod N), no exchange")
@@ -325,7 +326,8 @@ def main():
     # pass of the same frames (one batch lane: every launch alone on the chip, HIP events around each launch on the
     # stream it runs on) -- the same mode the kept rocprofv3 kernel trace under profiles/ is collected in.
     serial = None
-    if rank == 0 and world == 1 and scene.settings.gi:
+    if rank == 0 and world == 1 and scene.settings.gi and not args.no_serial_pass:
+        lanes_before = int(os.environ.get("FRAYHIP_PT_LANES", "4") or 4)       # the library's own default (render_state.hpp) unless the environment presets it
         scene.set_option("pt_lanes", 1)
         step()
         torch.cuda.synchronize()
@@ -339,7 +341,7 @@ def main():
         torch.cuda.synchronize()
         serial = {k: v / n_ser for k, v in acc.items()}
         serial["ms_per_step"] = (time.perf_counter() - t1) * 1e3 / n_ser
-        scene.set_option("pt_lanes", 4)
+        scene.set_option("pt_lanes", lanes_before)
 
     if rank == 0:
         from tools.source_hash import source_hash
@@ -409,9 +411,11 @@ def main():
         if transport:
             out["config"]["gather"] = transport
         # Counter-derived figures (HBM traffic, VALU issue and lane utilisation) cannot be collected by this process: they come
-        # from rocprofv3 --pmc passes of this same command (tools/profile_headline.sh -> profiles/pmc_latest.json) and are printed
-        # only when that profile was taken on the same device code (source hash) and workload; otherwise they stay null.
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        # from rocprofv3 --pmc passes of this same command (tools/profile_workload.sh -> profiles/pmc_latest_<workload>.json) and are
+        # printed only when that profile was taken on the same device code (source hash) and workload; otherwise they stay null.
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest_%s.json" % args.workload)
+        if not os.path.exists(pmc_path):
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if world == 1 and os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
@@ -424,7 +428,7 @@ def main():
                             out[key]["counters"] = k.get("derived")
                             out[key]["profile_avg_launch_ms"] = k.get("avg_launch_ms")
                 else:
-                    out["roofline"]["counters_note"] = "profiles/pmc_latest.json is for source %s / %s: not this build" % (pmc.get("source_hash"), pmc.get("workload"))
+                    out["roofline"]["counters_note"] = "%s is for source %s / %s: not this build" % (os.path.relpath(pmc_path, ROOT), pmc.get("source_hash"), pmc.get("workload"))
             except (KeyError, ValueError, OSError):
                 pass
         if not args.no_cpu_baseline and world == 1:

@@ -171,14 +171,16 @@ FD V3 ray_rdir(V3 d)
     rd.z = fabs(d.z) > 1e-12 ? 1.0 / d.z : 1e12;
     return rd;
 }
+template <int ST>
 FD void prepare_ray(LocalRay& lr)
 {
     if (lr.haveRd) return;
     lr.rd = ray_rdir(lr.d);
+    lr.haveRd = true;
+    if (!kd_variant(ST)) return;          // scenes without KD meshes test their few boxes with the reference's arithmetic (geom_intersect)
     lr.rmax = __builtin_fmax(__builtin_fmax(fabs(lr.rd.x), fabs(lr.rd.y)), fabs(lr.rd.z));
     lr.sMax = __builtin_fmax(__builtin_fmax(fabs(lr.s.x), fabs(lr.s.y)), fabs(lr.s.z));
     lr.dirOk = __builtin_fmin(__builtin_fmin(fabs(lr.d.x), fabs(lr.d.y)), fabs(lr.d.z)) >= 1e-6;
-    lr.haveRd = true;
 }
 
 // BBox::testIntersect, certified (dev_boxcert.hpp): decided from the ray's parameter interval against the box; the reference's
@@ -235,7 +237,7 @@ FD int kd_pop(KdStack& k)                            // caller checked sp > 0
 template <int ST>
 FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int& tri, double& l2, double& l3, Cnt& c)
 {
-    prepare_ray(lr);
+    prepare_ray<ST>(lr);
     const V3 s = lr.s, d = lr.d, rd = lr.rd;
     const CertRay cr = cert_ray(lr.rmax, lr.sMax, lr.dirOk, M.boxMax);
     Box6 box;
@@ -575,12 +577,19 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, LocalRay& lr, V3
     // mesh
     double gamma;
     if (N.tlTris > 0) {      // no KD-tree: Mesh::intersect's brute-force loop (mesh.cpp:146-161) on the node's own copy of the mesh header
-        prepare_ray(lr);
+        prepare_ray<ST>(lr);
         Box6 box;
         box.lox = N.bmin[0]; box.loy = N.bmin[1]; box.loz = N.bmin[2];
         box.hix = N.bmax[0]; box.hiy = N.bmax[1]; box.hiz = N.bmax[2];
-        TState st;
-        const bool rootHit = box_test_cert(box, lr, cert_ray(lr.rmax, lr.sMax, lr.dirOk, N.boxMax), st);
+        // Scenes without KD meshes (cornell_box: seven boxes per ray) keep the reference's arithmetic with its wave-uniform exits: there the
+        // interval form measured slower (headline 105.4 -> 109.1 ms: more registers, fewer waves).  Beside KD meshes the interval decides.
+        bool rootHit;
+        if constexpr (kd_variant(ST)) {
+            TState st;
+            rootHit = box_test_cert(box, lr, cert_ray(lr.rmax, lr.sMax, lr.dirOk, N.boxMax), st);
+        } else {
+            rootHit = box_test(box, ls, ld, lr.rd);
+        }
         STAMP(2);
         if (!rootHit) return false;
         gamma = 1e99;

@@ -35,9 +35,6 @@
 #ifndef FRAY_SHADOW_WAVES
 #define FRAY_SHADOW_WAVES 5     // the any-hit kernels at 96 VGPRs (13 / 8 spilled): boxed Whitted 12.0 -> 11.3 ms, headline -1 % against 4 waves
 #endif
-#ifndef FRAY_LEAN_WAVES_NOKD
-#define FRAY_LEAN_WAVES_NOKD 8  // k_primary and the any-hit kernels of scenes without KD meshes fit 64 VGPRs: ask for it, or the allocator spreads out to the KD variants' budget
-#endif
 #ifndef FRAY_BOUNCE_WAVES
 #define FRAY_BOUNCE_WAVES 4   // waves per SIMD the bounce kernel is register-allocated for: 128 VGPRs, 2 spilled (3 waves: 129 VGPRs; headline 123.5 vs 116.2 ms)
 #endif
@@ -185,7 +182,7 @@ static __global__ __launch_bounds__(256) void k_seed(DFrame F, int nItems, int s
 // ---- MODE_PRIMARY_ID ------------------------------------------------------------------------------
 struct PrimaryArgs { DScene S; DCamera C; DFrame F; int nItems; int32_t* hitId; double* hitDist; DStats* st; DCursors* cur; };
 template <int ST>
-static __global__ __launch_bounds__(256, kd_variant(ST) ? FRAY_PRIMARY_WAVES : FRAY_LEAN_WAVES_NOKD) void k_primary(PrimaryArgs A)
+static __global__ __launch_bounds__(256, FRAY_PRIMARY_WAVES) void k_primary(PrimaryArgs A)
 {
     Cnt c = zero_cnt();
     const int nItems = A.nItems;
@@ -442,7 +439,7 @@ static __global__ __launch_bounds__(256, FRAY_WH_SHADE_WAVES) void k_wh_shade(Wh
 
 struct WhVisibleArgs { DScene S; WhittedQueue Q; size_t N; int T; DStats* st; };
 template <int ST>
-static __global__ __launch_bounds__(256, kd_variant(ST) ? FRAY_SHADOW_WAVES : FRAY_LEAN_WAVES_NOKD) void k_wh_visible(WhVisibleArgs A)
+static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_wh_visible(WhVisibleArgs A)
 {
     Cnt c = zero_cnt();
     const size_t N = A.N;
@@ -836,7 +833,7 @@ static __global__ __launch_bounds__(256, kd_variant(ST) ? FRAY_BOUNCE_WAVES : FR
 // segment's radiance if it is unobstructed, black otherwise.
 struct ShadowArgs { DScene S; ShadowQueue SQ; QMetaRO meta; TermBuf TB; DStats* st; };
 template <int ST>
-static __global__ __launch_bounds__(256, kd_variant(ST) ? FRAY_SHADOW_WAVES : FRAY_LEAN_WAVES_NOKD) void k_pt_shadow(ShadowArgs A)
+static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(ShadowArgs A)
 {
     Cnt c = zero_cnt();
     const QMetaRO meta = A.meta;

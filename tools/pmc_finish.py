@@ -1,4 +1,4 @@
-"""Folds the passes of tools/profile_headline.sh into one record per kernel: average launch duration from the
+"""Folds the passes of tools/profile_workload.sh into one record per kernel: average launch duration from the
 kernel trace, HBM traffic from FETCH_SIZE / WRITE_SIZE, VALU issue / lane utilisation / wait fractions from the
 SQ counters, tagged with the source hash of the device code they were measured on.
 
@@ -31,16 +31,35 @@ def main():
         base = k.split("<")[0]
         if not base.startswith("k_"):
             continue
-        if "<" in k and k.split("<")[1].split(",")[0].split(">")[0].strip() != "0":
-            continue                      # only the uninstrumented variants (flag word 0) are the timed ones
+        if "<" in k:
+            flag = k.split("<")[1].split(",")[0].split(">")[0].strip()
+            if flag.lstrip("-").isdigit() and (int(flag) & 1):
+                continue                  # bit 0 of the flag word = the variant that maintains the work counters: only the others are the timed ones
         per = {c: e["total"] / max(1, e["launches"]) for c, e in v.items() if isinstance(e, dict) and "total" in e}
         rec = {"launches_profiled": max([e["launches"] for c, e in v.items() if isinstance(e, dict) and "launches" in e] or [0]), "per_launch": per}
         if k in dur:
             rec["avg_launch_ms"] = dur[k][1] / dur[k][0]
             rec["launches_traced"] = dur[k][0]
         d = {}
-        if "SQ_ACTIVE_INST_VALU" in per and per.get("GRBM_GUI_ACTIVE"):
-            d["valu_busy"] = per["SQ_ACTIVE_INST_VALU"] * 4.0 / (per["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        simd_cycles = per["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0 if per.get("GRBM_GUI_ACTIVE") else None     # GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs
+        if "SQ_ACTIVE_INST_VALU" in per and simd_cycles:
+            # waves' cycles with a vector instruction in flight, per SIMD cycle: two waves' 32-bit instructions overlap on a SIMD (2 of 4 cycles each),
+            # so this reaches 1 only for FP64 code and passes 1 for 32-bit integer code (k_seed) -- an upper estimate of VALU occupancy
+            d["valu_wave_active_per_simd_cycle"] = per["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles
+        if "SQ_INSTS_VALU" in per and simd_cycles:
+            # issue slots: every vector instruction holds its SIMD for 4 cycles (FP64, and a lone wave's 32-bit) or 2 (32-bit beside other waves): between x2 and x4
+            d["valu_issue_x4"] = per["SQ_INSTS_VALU"] * 4.0 / simd_cycles
+            d["valu_issue_x2"] = per["SQ_INSTS_VALU"] * 2.0 / simd_cycles
+        if "TA_TA_BUSY_sum" in per and per.get("GRBM_GUI_ACTIVE"):
+            d["ta_busy"] = per["TA_TA_BUSY_sum"] / (per["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)        # one texture-address unit per CU
+        if "TCP_TCP_TA_DATA_STALL_CYCLES_sum" in per and per.get("GRBM_GUI_ACTIVE"):
+            d["tcp_ta_data_stall"] = per["TCP_TCP_TA_DATA_STALL_CYCLES_sum"] / (per["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)
+        if "TCP_GATE_EN1_sum" in per and per.get("GRBM_GUI_ACTIVE"):
+            d["tcp_busy"] = per["TCP_GATE_EN1_sum"] / (per["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)
+        if "TCP_TOTAL_ACCESSES_sum" in per and per.get("TA_FLAT_READ_WAVEFRONTS_sum"):
+            d["l1_accesses_per_load_instruction"] = per["TCP_TOTAL_ACCESSES_sum"] / per["TA_FLAT_READ_WAVEFRONTS_sum"]     # cache lines one wave-wide load touches
+        if "TCP_TOTAL_ACCESSES_sum" in per and "TCP_TCC_READ_REQ_sum" in per and per["TCP_TOTAL_ACCESSES_sum"] > 0:
+            d["l1_hit_rate"] = 1.0 - per["TCP_TCC_READ_REQ_sum"] / per["TCP_TOTAL_ACCESSES_sum"]
         if "SQ_THREAD_CYCLES_VALU" in per and per.get("SQ_ACTIVE_INST_VALU"):
             d["lane_utilisation"] = per["SQ_THREAD_CYCLES_VALU"] / (64.0 * per["SQ_ACTIVE_INST_VALU"])
         if per.get("SQ_WAVE_CYCLES"):
@@ -51,8 +70,9 @@ def main():
             d["valu_insts_per_wave"] = per["SQ_INSTS_VALU"] / per["SQ_WAVES"]
         if "TCC_HIT_sum" in per and (per["TCC_HIT_sum"] + per.get("TCC_MISS_sum", 0)) > 0:
             d["l2_hit_rate"] = per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"])
-        d["formulas"] = ("valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); "
-                         "wait fractions over SQ_WAVE_CYCLES")
+        d["formulas"] = ("valu_wave_active_per_simd_cycle = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) (quad-cycles; > 1 possible for 32-bit code); "
+                         "valu_issue_xN = SQ_INSTS_VALU x N / SIMD cycles; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait fractions over SQ_WAVE_CYCLES; "
+                         "ta_busy / tcp_busy / tcp_ta_data_stall = *_sum / (GRBM_GUI_ACTIVE / 8 x 256 CUs)")
         rec["derived"] = d
         if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
             rec["hbm_bytes_per_launch"] = (per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024.0

@@ -169,7 +169,8 @@ def main():
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the serialised pass that times every launch alone (path tracing): durations then come from the timed region")
     ap.add_argument("--check", action="store_true", help="N > 1: also render the whole frame on rank 0 and require the gathered frame to equal it")
     ap.add_argument("--torch-gather", action="store_true", help="N > 1: exchange through torch.distributed.gather instead of frayhip_gather_buckets")
-    ap.add_argument("--shard-of", type=int, default=0, help="diagnosis on one GPU: render only rank 0's share of an N-rank run (buckets 0 mod N), no exchange")
+    ap.add_argument("--shard-of", type=int, default=0, help="diagnosis on one GPU: render only ONE rank's share of an N-rank run (buckets r mod N, r = --shard-rank), no exchange")
+    ap.add_argument("--shard-rank", type=int, default=0, help="with --shard-of N: whose share (tools/shard_balance.py measures every rank's)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the real multi-GPU run) or gloo (rehearsal: N ranks sharing GPU 0)")
     args = ap.parse_args()
 
@@ -252,7 +253,8 @@ def main():
         return torch.cuda.current_stream().cuda_stream
 
     def step(stats=False):
-        st = scene.render_device(frame.data_ptr(), seed=args.seed, bucket_first=rank, bucket_stride=args.shard_of if (args.shard_of > 1 and world == 1) else world,
+        shard = args.shard_of > 1 and world == 1
+        st = scene.render_device(frame.data_ptr(), seed=args.seed, bucket_first=args.shard_rank % args.shard_of if shard else rank, bucket_stride=args.shard_of if shard else world,
                                  spp_chunk=args.spp_chunk, stats=stats, stream=stream_ptr(), mode=mode,
                                  d_id_ptr=ids.data_ptr() if ids is not None else None,
                                  d_dist_ptr=dists.data_ptr() if dists is not None else None)
@@ -373,7 +375,7 @@ def main():
             "data": "reference scene file scenes/%s (unchanged), RNG contract seed %d" % (name, args.seed),
             "config": {"workload": desc_text, "width": W, "height": H, "spp": scene.samples_per_pixel(),
                        "rays_per_frame": rays_total, "camera_samples_per_frame": float(counts[2]),
-                       "parallelism": "tiles%d" % world if world > 1 else ("rank 0's share of tiles%d, no exchange (diagnosis)" % args.shard_of if args.shard_of > 1 else "single-gpu"),
+                       "parallelism": "tiles%d" % world if world > 1 else ("rank %d's share of tiles%d, no exchange (diagnosis)" % (args.shard_rank, args.shard_of) if args.shard_of > 1 else "single-gpu"),
                        "frame_ms": ms_per_step, "msamples_per_s": float(counts[2]) / (ms_per_step * 1e-3) / 1e6},
             # What bounds the dominant kernel is FP64 vector issue, not HBM: algorithmic FP64
             # operations per launch (SURVEY 8d operation counts x this frame's work counters) / average launch duration.

@@ -141,6 +141,17 @@ int ensure_work(frayhip_scene* sc, size_t bytes)
     return FRAYHIP_OK;
 }
 
+// The queue budget a frame may plan with: the tunable (pt_budget_mib), but never more than four fifths of what the device can still give
+// (free memory plus the workspace this scene already holds) -- on a smaller or busy GPU, or with several ranks sharing one for a
+// rehearsal, the frame is then cut into smaller batches instead of failing with E_NOMEM.
+size_t work_budget(const frayhip_scene* sc)
+{
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return sc->ptBudgetBytes;
+    const size_t avail = (freeB + sc->work_bytes) / 5 * 4;
+    return std::max<size_t>(std::min(sc->ptBudgetBytes, avail), (size_t)64 << 20);
+}
+
 hipEvent_t pool_event(std::vector<hipEvent_t>& pool, size_t i)
 {
     while (pool.size() <= i) {

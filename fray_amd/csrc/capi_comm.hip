@@ -40,10 +40,17 @@ Rccl* rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        // A process that already holds an RCCL (PyTorch maps its own copy) must keep exactly one: first ask for the copy that is
+        // already loaded (RTLD_NOLOAD binds it without loading anything), and only then load one.
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
-            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
             if (r.lib) break;
+        }
+        if (!r.lib && dlsym(RTLD_DEFAULT, "ncclCommInitRank")) r.lib = dlopen(nullptr, RTLD_NOW);   // linked into the process under another name
+        for (const char* n : names) {
+            if (r.lib) break;
+            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!r.lib) { r.why = std::string("RCCL is not available: ") + dlerror(); return; }
         auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p) r.why = std::string("RCCL lacks ") + n; return p; };
@@ -74,6 +81,7 @@ struct frayhip_comm {
     bool owned = true;
     float* d_stage = nullptr;       // root: one packed block per peer, back to back; other ranks: this rank's packed buckets
     size_t stage_floats = 0;
+    hipEvent_t stageFree = nullptr; // recorded after a gather's last use of d_stage: the next gather's stream waits for it, whatever stream that is
 };
 
 #define NCCL_TRY(expr)                                                                                          \
@@ -127,6 +135,7 @@ void frayhip_comm_destroy(frayhip_comm* c)
 {
     if (!c) return;
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->stageFree) (void)hipEventDestroy(c->stageFree);
     if (c->comm && c->owned) if (Rccl* R = rccl()) (void)R->CommDestroy(c->comm);
     delete c;
 }
@@ -145,8 +154,11 @@ int frayhip_gather_buckets(frayhip_comm* c, float* d_frame, int width, int heigh
     size_t need = 0;
     if (c->rank == root) { for (int r = 0; r < c->world; r++) if (r != root) need += floats_of(r); }
     else need = floats_of(c->rank);
+    // one staging buffer per communicator, whatever stream a gather runs on: a gather starts after the previous one's last use of it
+    if (!c->stageFree) HIP_TRY(hipEventCreateWithFlags(&c->stageFree, hipEventDisableTiming));
+    else HIP_TRY(hipStreamWaitEvent(stream, c->stageFree, 0));
     if (need > c->stage_floats) {
-        if (c->d_stage) (void)hipFree(c->d_stage);
+        if (c->d_stage) { HIP_TRY(hipEventSynchronize(c->stageFree)); (void)hipFree(c->d_stage); }
         c->d_stage = nullptr; c->stage_floats = 0;
         if (hipMalloc((void**)&c->d_stage, need * sizeof(float)) != hipSuccess) { set_error("frayhip_gather_buckets: out of device memory for the staging buffer"); return FRAYHIP_E_NOMEM; }
         c->stage_floats = need;
@@ -159,18 +171,24 @@ int frayhip_gather_buckets(frayhip_comm* c, float* d_frame, int width, int heigh
         hipLaunchKernelGGL(k_pack, dim3(grid_for_items(items)), dim3(256), 0, stream, F, items, channels, d_frame, c->d_stage, 0);
         HIP_TRY(hipGetLastError());
         NCCL_TRY(R->Send(c->d_stage, n, ncclFloat, root, c->comm, stream));
+        HIP_TRY(hipEventRecord(c->stageFree, stream));
         return FRAYHIP_OK;
     }
-    // root: every peer's block arrives concurrently (one point-to-point link each), then goes to its pixels
+    // root: every peer's block arrives concurrently (one point-to-point link each), then goes to its pixels.  An error inside the
+    // group must not leave it open (every later RCCL call of this thread -- torch's too -- would queue into a group that never ends):
+    // the first failure is remembered, the group is closed, then the failure is reported.
     NCCL_TRY(R->GroupStart());
     size_t off = 0;
-    for (int r = 0; r < c->world; r++) {
+    ncclResult_t failed = ncclSuccess;
+    for (int r = 0; r < c->world && failed == ncclSuccess; r++) {
         if (r == root) continue;
         const size_t n = floats_of(r);
-        if (n) NCCL_TRY(R->Recv(c->d_stage + off, n, ncclFloat, r, c->comm, stream));
+        if (n) failed = R->Recv(c->d_stage + off, n, ncclFloat, r, c->comm, stream);
         off += n;
     }
-    NCCL_TRY(R->GroupEnd());
+    const ncclResult_t ended = R->GroupEnd();
+    if (failed != ncclSuccess) { set_error(std::string("ncclRecv: ") + R->GetErrorString(failed)); return FRAYHIP_E_HIP; }
+    if (ended != ncclSuccess) { set_error(std::string("ncclGroupEnd: ") + R->GetErrorString(ended)); return FRAYHIP_E_HIP; }
     off = 0;
     for (int r = 0; r < c->world; r++) {
         if (r == root) continue;
@@ -183,7 +201,15 @@ int frayhip_gather_buckets(frayhip_comm* c, float* d_frame, int width, int heigh
         off += n;
     }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->stageFree, stream));
     return FRAYHIP_OK;
+}
+
+// Can this host exchange through RCCL at all?  Every rank asks before any rank enters ncclCommInitRank (which blocks until all
+// ranks have arrived): a rank without RCCL then makes all of them choose the other transport instead of leaving the rest waiting.
+int frayhip_comm_available(void)
+{
+    return rccl() ? 1 : 0;
 }
 
 }  // extern "C"

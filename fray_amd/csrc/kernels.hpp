@@ -14,8 +14,8 @@
 //                  path queue (ballot rank, no global counter)
 //   k_scan         per-wave survivor counts -> segment offsets (path queue and shadow queue)
 //   k_pt_shadow    visible() for every queued next-event segment: the sample's radiance term of this bounce
-//   k_pt_fold      a sample's radiance from its terms, innermost first
-//   k_pt_resolve   per pixel, samples summed in sample order (the reference's FP32 order)
+//   k_pt_resolve_terms   mono: per pixel, every sample's terms added innermost first and the samples in sample order (the reference's FP32 order)
+//   k_pt_fold, k_pt_resolve   stereo (two passes share the term lists): a sample's radiance from its terms; then the per-pixel sum and the anaglyph blend
 //   k_pack         bucket-major <-> row-major copies for the multi-GPU gather (dev_pack.hpp)
 #pragma once
 #include "dev_shade.hpp"
@@ -881,6 +881,34 @@ static __global__ __launch_bounds__(256) void k_pt_fold(TermBuf TB, uint32_t tot
         }
         const size_t o = (size_t)slot * 3;
         sampleRad[o] = result.r; sampleRad[o + 1] = result.g; sampleRad[o + 2] = result.b;
+    }
+}
+
+// The mono frame's fold and resolve in one pass: per pixel, every sample's terms are added innermost first (k_pt_fold's order) and the samples
+// in sample order (k_pt_resolve's), without the per-sample radiance making a round trip through memory.
+static __global__ __launch_bounds__(256) void k_pt_resolve_terms(DFrame F, int nItems, int s0, int chunk, TermBuf TB, float* __restrict__ sum, float* __restrict__ rgb)
+{
+    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < nItems; item += gridDim.x * blockDim.x) {
+        int x, y;
+        if (!item_pixel(F, item, x, y)) continue;
+        const size_t si = (size_t)item * 3;
+        C3 a = s0 == 0 ? c3(0, 0, 0) : c3(sum[si], sum[si + 1], sum[si + 2]);
+        for (int s = 0; s < chunk; s++) {
+            const uint32_t slot = (uint32_t)s * (uint32_t)nItems + (uint32_t)item;
+            C3 result = c3(0, 0, 0);
+            for (int k = (int)TB.n[slot] - 1; k >= 0; k--) {
+                const size_t q = (size_t)k * 3 * TB.nPaths + slot;
+                result = c3(TB.t[q], TB.t[q + TB.nPaths], TB.t[q + 2 * (size_t)TB.nPaths]) + result;
+            }
+            a = a + result;
+        }
+        if (s0 + chunk >= F.spp) {
+            a = a / (float)F.spp;
+            const size_t p = ((size_t)y * F.W + x) * 3;
+            rgb[p] = a.r; rgb[p + 1] = a.g; rgb[p + 2] = a.b;
+        } else {
+            sum[si] = a.r; sum[si + 1] = a.g; sum[si + 2] = a.b;
+        }
     }
 }
 

@@ -123,7 +123,8 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 const size_t colBytes = r256((size_t)grid * 256 * 624 * sizeof(uint32_t));
                 // per (pixel, sample): base 12 + a 24 + hit 1 + radiance 12 per eye, 37 per light sample and eye, 4 for the seed
                 const size_t perSlot = eyes * (49 + (size_t)T * 37) + 4;
-                const size_t budget = sc->ptBudgetBytes > colBytes + (64u << 20) ? sc->ptBudgetBytes - colBytes : (64u << 20);
+                const size_t wb = work_budget(sc);
+                const size_t budget = wb > colBytes + (64u << 20) ? wb - colBytes : (64u << 20);
                 int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / ((size_t)nItems * perSlot));
                 if (chunk > spp) chunk = spp;
                 while (chunk > 1 && (size_t)nItems * chunk * eyes * (size_t)std::max(T, 1) > ((size_t)1 << 31)) chunk /= 2;
@@ -179,7 +180,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             // a small frame (an eighth of 1080p x 64 spp, i.e. one rank's share of an 8-rank run) is cut into fewer, larger batches:
             // measured 15.5 ms on three lanes against 15.9 on four; from a quarter of that frame upwards four lanes win
             if (maxLanes > 3 && (size_t)nItems * (size_t)spp < ((size_t)24 << 20)) maxLanes = 3;
-            const size_t budget = std::max<size_t>(sc->ptBudgetBytes / perPath, 1);       // paths in flight over all lanes
+            const size_t budget = std::max<size_t>(work_budget(sc) / perPath, 1);       // paths in flight over all lanes
             int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / maxLanes / (size_t)nItems);
             if (chunk > spp) chunk = spp;
             if (f->spp_chunk <= 0 && spp >= 2 * maxLanes && chunk * maxLanes > spp) chunk = (spp + maxLanes - 1) / maxLanes;   // enough batches to fill the lanes
@@ -267,13 +268,15 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                         HIP_TRY(hipEventRecord(ed, ls));
                         nShadowEvents += 2;
                     }
-                    // the samples' terms -> their radiance, in the reference's innermost-first order
-                    hipLaunchKernelGGL(k_pt_fold, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, ls, TermBuf{L.terms, L.termCount, (uint32_t)nPaths, 0},
-                                       (uint32_t)((size_t)nItems * cn), rad);
+                    // the samples' terms -> their radiance, in the reference's innermost-first order.  A stereo frame's two passes share the
+                    // term lists, so each pass folds its own; a mono frame folds inside the resolve below
+                    if (stereo) hipLaunchKernelGGL(k_pt_fold, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, ls, TermBuf{L.terms, L.termCount, (uint32_t)nPaths, 0},
+                                                   (uint32_t)((size_t)nItems * cn), rad);
                 }
                 // the running per-pixel sum takes the batches in sample order
                 if (batch > 0 && nLanes > 1) HIP_TRY(hipStreamWaitEvent(ls, sc->evResolved[(batch - 1) % nLanes], 0));
-                hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, ls, F, C, set.saturation, nItems, s0, cn, L.sampleRad, L.sampleRadR, sum, d_rgb);
+                if (stereo) hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, ls, F, C, set.saturation, nItems, s0, cn, L.sampleRad, L.sampleRadR, sum, d_rgb);
+                else hipLaunchKernelGGL(k_pt_resolve_terms, dim3(grid_for(nItems)), dim3(256), 0, ls, F, nItems, s0, cn, TermBuf{L.terms, L.termCount, (uint32_t)nPaths, 0}, sum, d_rgb);
                 HIP_TRY(hipEventRecord(sc->evResolved[batch % nLanes], ls));
             }
             // the last resolve follows every earlier one, and each resolve is the last launch of its batch

@@ -74,6 +74,7 @@ constexpr size_t kStatsBytes = kCursorOffset + sizeof(DCursors);
 
 DCamera camera_begin_frame(const frayhip_camera& c, int W, int H);
 int persistent_grid(size_t n, int wavesPerSimd);
+size_t work_budget(const frayhip_scene* sc);
 int bounce_grid(size_t n);
 int grid_for(size_t n);
 int ensure_work(frayhip_scene* sc, size_t bytes);

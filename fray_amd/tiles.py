@@ -42,6 +42,16 @@ class LibraryGather:
     def __init__(self, rank, world, dist, dst=0):
         lib = _scene.lib
         self.rank, self.world, self.dst = rank, world, dst
+        # ncclCommInitRank blocks until every rank has entered it: a rank that cannot bind RCCL must make ALL ranks give up here, before any
+        # of them goes in (the caller then switches every rank to the other transport together)
+        have = [bool(lib.frayhip_comm_available())]
+        if world > 1:
+            every = [None] * world
+            dist.all_gather_object(every, have[0])
+            if not all(every):
+                raise _scene.FrayError(-4, "RCCL cannot be bound on rank(s) %s" % [r for r, ok in enumerate(every) if not ok])
+        elif not have[0]:
+            raise _scene.FrayError(-4, "RCCL cannot be bound in this process")
         ident = [None]
         if rank == 0:
             buf = (C.c_char * 128)()

@@ -312,9 +312,14 @@ int  frayhip_unpack_buckets_device(const float* d_packed, float* d_frame, int wi
  *                            means the host has (MPI, a file, torch.distributed, a socket)
  *   frayhip_comm_create      every rank, with the same id; world == 1 needs no id and no RCCL
  *   frayhip_comm_from_nccl   wraps an ncclComm_t the host already owns (not destroyed by frayhip_comm_destroy)
- * RCCL is bound at run time: FRAYHIP_E_UNSUPPORTED when the host has none. */
+ *   frayhip_comm_available   1 when RCCL can be bound in this process, 0 otherwise: frayhip_comm_create blocks inside
+ *                            ncclCommInitRank until EVERY rank has entered it, so the ranks agree on this first
+ * RCCL is bound at run time (an RCCL the process already holds is used, none is loaded beside it): FRAYHIP_E_UNSUPPORTED
+ * when the host has none.  Gathers on one communicator share its staging buffer; a gather waits, on its own stream,
+ * for the previous gather of that communicator, so they may be issued on different streams. */
 #define FRAYHIP_COMM_ID_BYTES 128
 typedef struct frayhip_comm frayhip_comm;
+int  frayhip_comm_available(void);
 int  frayhip_comm_unique_id(void* id128);
 int  frayhip_comm_create(const void* id128, int rank, int world, frayhip_comm** out);
 int  frayhip_comm_from_nccl(void* nccl_comm, int rank, int world, frayhip_comm** out);

@@ -60,6 +60,50 @@ def test_library_gather_single_rank_and_argument_checks(fray, gpu):
     assert lib.frayhip_comm_create(bytes(ident), 2, 2, C.byref(bad)) != 0                      # rank outside the world
 
 
+def test_comm_available_reports_rccl(fray, gpu):
+    """frayhip_comm_available: what every rank asks before any rank enters ncclCommInitRank (fray_amd/tiles.py LibraryGather)."""
+    assert fray.lib.frayhip_comm_available() == 1
+
+
+def test_mgpu_example_with_one_rank_writes_the_single_gpu_picture(tmp_path):
+    """examples/fray_render_mgpu (one process per GPU, frayhip_gather_buckets as the exchange) with N = 1 must write, byte for byte,
+    the BMP examples/fray_render writes: the fork / communicator / gather plumbing around the same frame."""
+    import subprocess
+    one, many = os.path.join(ROOT, "examples", "fray_render"), os.path.join(ROOT, "examples", "fray_render_mgpu")
+    if not (os.path.exists(one) and os.path.exists(many)):
+        pytest.fail("examples are not built (make)")
+    scene = os.path.join(ROOT, "scenes", "cornell_box.fray")
+    a, b = tmp_path / "one.bmp", tmp_path / "mgpu.bmp"
+    r1 = subprocess.run([one, scene, str(a), "96", "64", "4"], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr
+    r2 = subprocess.run([many, scene, str(b), "96", "64", "4", "1"], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
+@pytest.mark.parametrize("workload,spp", [("cornell", 64), ("forest_dof", 16)])
+def test_union_of_eight_shards_equals_the_full_frame_at_full_size(fray, gpu, workload, spp):
+    """What an 8-rank run computes, on one GPU: the eight bucket shards (b = r mod 8) rendered one after the other into one frame must
+    equal, bit for bit, the frame rendered in one call -- 1920x1080, one path-traced and one Whitted (DOF) configuration."""
+    import fray_amd
+    W, H = 1920, 1080
+    if workload == "cornell":
+        s = fray_amd.Scene.parseScene(os.path.join(ROOT, "scenes", "cornell_box.fray"))
+        s.settings.gi, s.settings.numPaths = 1, spp
+    else:
+        s = fray_amd.Scene.parseScene(os.path.join(ROOT, "scenes", "forest.fray"))
+        s.settings.wantAA, s.settings.interactive = 0, 0
+        s.camera.dof, s.camera.numDOFSamples = 1, spp
+    s.settings.frameWidth, s.settings.frameHeight = W, H
+    s.beginRender()
+    whole, _ = s.render(seed=42)
+    parts = np.zeros_like(whole)
+    for r in range(8):
+        s.render(seed=42, bucket_first=r, bucket_stride=8, out=parts)
+    assert np.array_equal(whole, parts)
+    s.close()
+
+
 def test_bench_line_contract_single_gpu(tmp_path):
     """`python bench.py` (N = 1, a short run) prints ONE JSON line with the fields the driver reads, the roofline of the dominant
     kernel with non-overlapped launch durations, and the CPU baseline with its in-run parity check."""

@@ -89,10 +89,10 @@ def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0, gpu_frame=None):
     if gpu_frame is not None:
         # the buckets the oracle just rendered, against the same pixels of the frame the GPU was timed on
         import numpy as np
-        BW = (W - 1) // 48 + 1
+        from fray_amd import tiles
         mask = np.zeros((H, W), bool)
         for b in range(0, nb, stride):
-            by, bx = divmod(b, BW)
+            bx, by = tiles.bucket_xy(W, H, b)
             mask[by * 48:by * 48 + 48, bx * 48:bx * 48 + 48] = True
         d = gpu_frame[mask].astype(np.float64) - cpu_img[mask]
         parity = {"pixels": int(mask.sum()), "rms_per_channel": [float(v) for v in np.sqrt((d ** 2).mean(axis=0))],

@@ -167,6 +167,7 @@ SYMBOLS = {
     "frayhip_bucket_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "frayhip_pack_buckets_device": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "frayhip_unpack_buckets_device": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "frayhip_bucket_xy": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "frayhip_comm_available": (C.c_int, []),
     "frayhip_comm_unique_id": (C.c_int, [VP]),
     "frayhip_comm_create": (C.c_int, [VP, C.c_int, C.c_int, P(VP)]),

@@ -44,6 +44,16 @@ int frayhip_bucket_count(int width, int height, int bucket_first, int bucket_str
     return (total - bucket_first + bucket_stride - 1) / bucket_stride;
 }
 
+int frayhip_bucket_xy(int width, int height, int bucket, int* bx, int* by)
+{
+    if (width <= 0 || height <= 0 || !bx || !by) return FRAYHIP_E_ARG;
+    const int BW = (width - 1) / 48 + 1, BH = (height - 1) / 48 + 1;
+    if (bucket < 0 || bucket >= BW * BH) return FRAYHIP_E_ARG;
+    *by = bucket / BW;
+    *bx = (bucket % BW + FRAYHIP_BUCKET_SKEW * *by) % BW;
+    return FRAYHIP_OK;
+}
+
 // convertTo8bit / Color::toRGB32 (color.h:29-34, 59-65): clamp, floor(x*255 + 0.5), 0x00RRGGBB.
 int frayhip_to_rgb32(const float* rgb, uint32_t* out, int n_pixels)
 {

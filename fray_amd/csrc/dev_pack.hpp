@@ -9,7 +9,7 @@ FD bool packed_pixel(const DFrame& F, int item, int& x, int& y)
 {
     int k = item / 2304, local = item - k * 2304;
     int b = F.bucketFirst + k * F.bucketStride;
-    int bx = b % F.BW, by = b / F.BW;
+    int by = b / F.BW, bx = (b - by * F.BW + FRAYHIP_BUCKET_SKEW * by) % F.BW;      // frayhip_bucket_xy (include/frayhip.h)
     x = bx * 48 + local % 48;
     y = by * 48 + local / 48;
     return x < F.W && y < F.H;

@@ -14,6 +14,7 @@
 //    fetched through the scalar cache.
 #pragma once
 #include <stdint.h>
+#include "frayhip.h"      // FRAYHIP_BUCKET_SKEW: the bucket numbering is part of the C ABI
 
 // Scene tables are read-only for the whole frame.  On the device their pointers are typed into the
 // constant address space (4): loads through them are known not to alias the kernels' stores, so a

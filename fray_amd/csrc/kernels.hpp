@@ -64,7 +64,7 @@ FD bool item_pixel(const DFrame& F, int item, int& x, int& y)
 {
     int k = item / 2304, local = item - k * 2304;
     int b = F.bucketFirst + k * F.bucketStride;
-    int bx = b % F.BW, by = b / F.BW;
+    int by = b / F.BW, bx = (b - by * F.BW + FRAYHIP_BUCKET_SKEW * by) % F.BW;      // frayhip_bucket_xy (include/frayhip.h)
     int tile = local >> 6, in = local & 63;
     x = bx * 48 + (tile % 6) * 8 + (in & 7);
     y = by * 48 + (tile / 6) * 8 + (in >> 3);

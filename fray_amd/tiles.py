@@ -20,6 +20,14 @@ def bucket_count(W, H, first, stride):
     return n
 
 
+def bucket_xy(W, H, b):
+    """Bucket column and row of bucket b (include/frayhip.h: rows rotated against each other by FRAYHIP_BUCKET_SKEW)."""
+    bx, by = C.c_int(), C.c_int()
+    if _scene.lib.frayhip_bucket_xy(W, H, b, C.byref(bx), C.byref(by)):
+        raise ValueError("bad bucket")
+    return bx.value, by.value
+
+
 def device_pack(frame, W, H, rank, world, out, stream=None):
     rc = _scene.lib.frayhip_pack_buckets_device(frame.data_ptr(), out.data_ptr(), W, H, frame.shape[-1], rank, world, stream)
     if rc:

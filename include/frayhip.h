@@ -199,9 +199,16 @@ enum {
 
 /* Frame size is settings.frameWidth x frameHeight (the reference takes it from the SDL
  * surface created with those values, sdl.cpp:77-88, main.cpp:508).  Work is split in the
- * reference's 48x48 buckets (sdl.cpp:243-262, row-major bucket index by*BW+bx); a call renders
- * the buckets b with b % bucket_stride == bucket_first, so N ranks with stride N cover the
- * frame.  Pixels of other buckets are left untouched in the output buffers. */
+ * reference's 48x48 buckets (sdl.cpp:243-262); a call renders the buckets b with
+ * b % bucket_stride == bucket_first, so N ranks with stride N cover the frame.  Pixels of other
+ * buckets are left untouched in the output buffers.
+ * Bucket b of a frame BW = ceil(W / 48) buckets wide is the one in bucket row by = b / BW and bucket
+ * column bx = (b % BW + FRAYHIP_BUCKET_SKEW * by) % BW (frayhip_bucket_xy): every bucket row is rotated
+ * against the one above it, so that a stride that divides BW (8 ranks on a 1920-wide frame: BW = 40)
+ * deals diagonal stripes, not eight fixed sets of columns -- with plain row-major numbering rank r
+ * would own the same five columns in every row, and the slowest rank's share of forest.fray was 8 %
+ * above the mean. */
+#define FRAYHIP_BUCKET_SKEW 3
 typedef struct frayhip_frame {
     int32_t  mode;
     uint32_t seed;               /* RNG contract seed; the reference uses 42   */
@@ -298,6 +305,7 @@ int  frayhip_render_device(frayhip_scene* s, const frayhip_frame* f,
  * frayhip_bucket_count(W,H,first,stride) * 48*48*channels floats; unpack is the inverse and
  * is run by the gathering rank once per peer. */
 int  frayhip_bucket_count(int width, int height, int bucket_first, int bucket_stride);
+int  frayhip_bucket_xy(int width, int height, int bucket, int* bx, int* by);   /* bucket column and row of bucket b (the rule above) */
 int  frayhip_pack_buckets_device(const float* d_frame, float* d_packed, int width, int height,
                                  int channels, int bucket_first, int bucket_stride, void* hip_stream);
 int  frayhip_unpack_buckets_device(const float* d_packed, float* d_frame, int width, int height,

@@ -987,7 +987,7 @@ int fray_oracle_render(const frayhip_scene_desc* desc, const frayhip_frame* f, f
         while (true) {
             int k = cursor++;
             if (k >= (int)buckets.size()) break;
-            int bx = buckets[k] % BW, by = buckets[k] / BW;
+            int by = buckets[k] / BW, bx = (buckets[k] % BW + FRAYHIP_BUCKET_SKEW * by) % BW;   // the bucket numbering of include/frayhip.h
             int x1 = std::min(W, (bx + 1) * 48), y1 = std::min(H, (by + 1) * 48);
             for (int y = by * 48; y < y1; y++)
                 for (int x = bx * 48; x < x1; x++) {

@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 SCENES = os.path.join(ROOT, "scenes")
 
 
+def bucket_xy(W, b):
+    """Bucket column and row of bucket b, restated from include/frayhip.h: by = b / BW, bx = (b % BW + FRAYHIP_BUCKET_SKEW * by) % BW
+    with FRAYHIP_BUCKET_SKEW = 3 (tests/test_abi.py checks this restatement against frayhip_bucket_xy)."""
+    BW = (W - 1) // 48 + 1
+    by = b // BW
+    return (b % BW + 3 * by) % BW, by
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
     # A clean launcher for tests that start other programs (torch.distributed.run + bench.py): the fork server is started now,

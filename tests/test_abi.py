@@ -140,3 +140,28 @@ def test_scene_create_range_checks_a_description_before_touching_the_gpu(fray, a
     def bad_frame(d):
         d.settings.frameWidth = 0
     expect_rejected(bad_frame, "frame size")
+
+
+def test_bucket_numbering_is_the_documented_one(fray):
+    """frayhip_bucket_xy: bucket b sits in bucket row b / BW and column (b % BW + 3 * row) % BW (include/frayhip.h, FRAYHIP_BUCKET_SKEW): the
+    rule the tests restate (conftest.bucket_xy) is the library's for every bucket of a few frame sizes, it is a bijection, and a stride
+    that divides the frame's width in buckets (8 ranks, 1920 pixels) deals every rank a bucket in every residue class of columns."""
+    import ctypes as C
+    from conftest import bucket_xy
+    for W, H in [(1920, 1080), (640, 480), (100, 75), (4096, 4096), (47, 49)]:
+        BW, BH = (W - 1) // 48 + 1, (H - 1) // 48 + 1
+        seen = set()
+        for b in range(BW * BH):
+            bx, by = C.c_int(), C.c_int()
+            assert fray.lib.frayhip_bucket_xy(W, H, b, C.byref(bx), C.byref(by)) == 0
+            assert (bx.value, by.value) == bucket_xy(W, b)
+            assert 0 <= bx.value < BW and 0 <= by.value < BH
+            seen.add((bx.value, by.value))
+        assert len(seen) == BW * BH
+        bx, by = C.c_int(), C.c_int()
+        assert fray.lib.frayhip_bucket_xy(W, H, BW * BH, C.byref(bx), C.byref(by)) != 0
+    cols = {r: set() for r in range(8)}
+    for b in range(40 * 23):
+        x, _ = bucket_xy(1920, b)
+        cols[b % 8].add(x % 8)
+    assert all(len(c) == 8 for c in cols.values())

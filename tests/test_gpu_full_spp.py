@@ -8,7 +8,7 @@ camera-sample counters must be exact on both sides."""
 import numpy as np
 import pytest
 
-from conftest import open_scene
+from conftest import bucket_xy, open_scene
 
 pytestmark = pytest.mark.gpu
 RMS_TOL = 1e-4          # per channel, north_star
@@ -35,7 +35,7 @@ def test_full_spp_frame_vs_oracle_buckets(fray, abi, oracle, gpu, scene, W, H, o
     BW, BH = (W - 1) // 48 + 1, (H - 1) // 48 + 1
     mask = np.zeros((H, W), bool)
     for b in range(first, BW * BH, stride):
-        by, bx = divmod(b, BW)
+        bx, by = bucket_xy(W, b)
         mask[by * 48:by * 48 + 48, bx * 48:bx * 48 + 48] = True
     assert mask.sum() >= 3 * 2304 - 48 * 48             # at least three buckets (a ragged edge bucket may be smaller)
     assert ost["samples"] == int(mask.sum()) * spp

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ROOT, open_scene
+from conftest import ROOT, bucket_xy, open_scene
 
 pytestmark = pytest.mark.gpu
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "primary_hashes.json")))
@@ -429,7 +429,7 @@ def test_pack_unpack_buckets(fray, gpu):
         f = frame.cpu().numpy()
         for k in range(nb):
             b = r + k * world
-            bx, by = b % BW, b // BW
+            bx, by = bucket_xy(W, b)
             tile = np.zeros((48, 48, 3), np.float32)
             sub = f[by * 48:by * 48 + 48, bx * 48:bx * 48 + 48]
             tile[:sub.shape[0], :sub.shape[1]] = sub
@@ -547,7 +547,7 @@ def test_full_size_frames_of_the_other_configs(fray, abi, oracle, gpu, scene, W,
     BW, BH = (W - 1) // 48 + 1, (H - 1) // 48 + 1
     mask = np.zeros((H, W), bool)
     for bk in range(first, BW * BH, stride):
-        bx, by = bk % BW, bk // BW
+        bx, by = bucket_xy(W, bk)
         mask[by * 48:by * 48 + 48, bx * 48:bx * 48 + 48] = True
     assert mask.sum() > 20000
     d = (a[mask].astype(np.float64) - ref[mask]) ** 2

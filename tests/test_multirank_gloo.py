@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from conftest import ROOT, SCENES
+from conftest import ROOT, SCENES, bucket_xy
 
 
 def np_pack(frame, W, H, rank, world, out):
@@ -20,7 +20,7 @@ def np_pack(frame, W, H, rank, world, out):
     nb_total = BW * ((H - 1) // 48 + 1)
     o = out.numpy().reshape(-1, 48, 48, C)
     for k, b in enumerate(range(rank, nb_total, world)):
-        bx, by = b % BW, b // BW
+        bx, by = bucket_xy(W, b)
         tile = np.zeros((48, 48, C), np.float32)
         sub = f[by * 48:by * 48 + 48, bx * 48:bx * 48 + 48]
         tile[:sub.shape[0], :sub.shape[1]] = sub
@@ -34,7 +34,7 @@ def np_unpack(packed, frame, W, H, rank, world):
     nb_total = BW * ((H - 1) // 48 + 1)
     p = packed.numpy().reshape(-1, 48, 48, C)
     for k, b in enumerate(range(rank, nb_total, world)):
-        bx, by = b % BW, b // BW
+        bx, by = bucket_xy(W, b)
         sub = f[by * 48:by * 48 + 48, bx * 48:bx * 48 + 48]
         sub[...] = p[k][:sub.shape[0], :sub.shape[1]]
 

@@ -354,6 +354,8 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     }
     size_t oNodes = A.add(nullptr, 0);                  // filled after the meshes: tree-less nodes hold a device pointer
     A.host.resize(oNodes + nodes.size() * sizeof(DNode));
+    size_t oGates = A.add(nullptr, 0);                  // the path tracer's scheduling hint (DGate), filled with the nodes
+    A.host.resize(oGates + FRAY_MAX_GATES * sizeof(DGate));
     std::vector<DPlane> planes(d.n_planes);
     for (int i = 0; i < d.n_planes; i++) { planes[i].limit = d.planes[i].limit; planes[i].height = d.planes[i].height; }
     size_t oPlanes = A.add(planes.data(), planes.size() * sizeof(DPlane));
@@ -531,6 +533,28 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         }
     }
     if (!nodes.empty()) memcpy(A.host.data() + oNodes, nodes.data(), nodes.size() * sizeof(DNode));
+    // gates: world-space boxes of the meshes whose brute-force triangle loops are worth skipping for a whole wave (dev_scene.hpp DGate):
+    // the eight corners of the mesh's box through the node's transform (Transform::transformPoint, matrix.cpp:137-146), a hair wider
+    int nGates = 0;
+    {
+        DGate gates[FRAY_MAX_GATES];
+        for (int i = 0; i < d.n_nodes && nGates < FRAY_MAX_GATES; i++) {
+            const DNode& N = nodes[i];
+            if (N.tlTris < FRAY_GATE_MIN_TRIS) continue;
+            DGate g;
+            for (int k = 0; k < 3; k++) { g.lo[k] = 1e300; g.hi[k] = -1e300; }
+            for (int c = 0; c < 8; c++) {
+                const double p[3] = {c & 1 ? N.bmax[0] : N.bmin[0], c & 2 ? N.bmax[1] : N.bmin[1], c & 4 ? N.bmax[2] : N.bmin[2]};
+                for (int k = 0; k < 3; k++) {
+                    const double w = p[0] * N.T.m[k] + p[1] * N.T.m[3 + k] + p[2] * N.T.m[6 + k] + N.T.off[k];
+                    g.lo[k] = std::min(g.lo[k], w); g.hi[k] = std::max(g.hi[k], w);
+                }
+            }
+            for (int k = 0; k < 3; k++) { const double e = 1e-6 * (1.0 + std::fabs(g.lo[k]) + std::fabs(g.hi[k])); g.lo[k] -= e; g.hi[k] += e; }
+            gates[nGates++] = g;
+        }
+        if (nGates) memcpy(A.host.data() + oGates, gates, (size_t)nGates * sizeof(DGate));
+    }
     for (int i = 0; i < d.n_textures; i++) tex[i].texels = (const FRAY_RO float*)(base + oTexels) + d.textures[i].texel_offset;
     if (!tex.empty()) memcpy(A.host.data() + oTex, tex.data(), tex.size() * sizeof(DTexture));
     hipError_t e = hipMemcpy(sc->d_arena, A.host.data(), A.host.size(), hipMemcpyHostToDevice);
@@ -539,6 +563,8 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
 
     DScene& S = sc->S;
     S.nodes = (const FRAY_RO DNode*)(base + oNodes);
+    S.gates = (const FRAY_RO DGate*)(base + oGates);
+    S.nGates = nGates; S.padGates = 0;
     S.planes = (const FRAY_RO DPlane*)(base + oPlanes);
     S.spheres = (const FRAY_RO DSphere*)(base + oSpheres);
     S.cubes = (const FRAY_RO DCube*)(base + oCubes);

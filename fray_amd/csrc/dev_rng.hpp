@@ -144,16 +144,22 @@ struct MtLong {
         for (int k = 227; k < 623; k++) w(k) = w(k - 227) ^ tw(w(k), w(k + 1));
         w(623) = w(396) ^ tw(w(623), w(0));
     }
+    // The full state after the first twist, in the thread's workspace column.  A function of the seed alone, so it may be made before the
+    // register stream has reached its 227th word (k_whitted does that for a whole wave at once: made lane by lane, as each lane's glossy
+    // rejection loop happens to cross 227 words, the 1 248-step dependent chain below ran up to 64 times per 8x8 tile -- 22 ms for one tile
+    // at the horizon of hw9/dragon.fray).
+    FD void materialise()
+    {
+        uint32_t x = seed;
+        w(0) = x;
+        for (uint32_t i = 1; i < 624; i++) { x = mt_lcg(x, i); w((int)i) = x; }
+        twist();
+        idx = 227;
+    }
     FD uint32_t next()
     {
         if (r.j < 227) return mt_next(r);
-        if (idx < 0) {                       // materialise: seeding recurrence, then the first twist
-            uint32_t x = seed;
-            w(0) = x;
-            for (uint32_t i = 1; i < 624; i++) { x = mt_lcg(x, i); w((int)i) = x; }
-            twist();
-            idx = 227;
-        }
+        if (idx < 0) materialise();
         if (idx >= 624) { twist(); idx = 0; }
         uint32_t v = w(idx++);
         v ^= v >> 11;

@@ -146,8 +146,19 @@ struct DCamera {
     int32_t dof, pad;
 };
 
+// Scheduling hint for the path tracer's queues (kernels.hpp, ray_gate_class): the world-space bounding boxes of the nodes whose triangle loops
+// are worth skipping for a whole wave -- meshes without a KD-tree and with FRAY_GATE_MIN_TRIS triangles or more (cornell_box: the two
+// blocks).  A ray that misses all of them goes to the front of its wave's queue segment, the others to the back, so that the waves of the next
+// launch are (nearly) all-miss or all-pass and the all-miss ones skip those loops at the wave-uniform root box test.  A hint only: every ray
+// still runs the reference's tests on every node.
+#define FRAY_MAX_GATES 8
+#define FRAY_GATE_MIN_TRIS 6
+struct DGate { double lo[3], hi[3]; };
+
 struct DScene {
     const FRAY_RO DNode* nodes;
+    const FRAY_RO DGate* gates;
+    int32_t nGates, padGates;
     const FRAY_RO DPlane* planes;
     const FRAY_RO DSphere* spheres;
     const FRAY_RO DCube* cubes;

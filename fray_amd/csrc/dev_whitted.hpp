@@ -20,140 +20,148 @@ struct WFrame {
 
 #define FRAY_WSTACK 40
 
-template <int ST, class G>
-FD C3 raytrace_full(const DScene& S, V3 o0, V3 d0, G& tab, Cnt& c, bool& overflow)
-{
+// One lane's raytrace() machine.  `mode` says where the lane stands; the kernel (k_whitted, kernels.hpp) drives all lanes of a wave
+// through rounds -- every lane takes its cheap steps (wl_cheap_step: returns, loop heads of glossy / layered activations, pushes of
+// recursive shaders) until each stands at a closest-hit search (WM_TRACE), at a direct-light loop (WM_SHADE of a Constant / Lambert /
+// Phong surface) or at the end of its camera ray (WM_ROOT_RET); then ONE search runs for the whole wave, then ONE direct-light loop.
+// A lane's own sequence of steps, random draws and FP32 colour operations is the reference's depth-first call tree.
+enum { WM_TRACE = 0, WM_SHADE = 1, WM_RET = 2, WM_RESUME = 3, WM_ROOT_RET = 4, WM_NEXT_SAMPLE = 5, WM_NEXT_PIXEL = 6, WM_EXHAUSTED = 7 };
+struct WhittedLane {
     WFrame stack[FRAY_WSTACK];
-    int sp = 0;
-    // registers of the machine
-    V3 o = o0, d = d0;
-    int depth = 0;
+    int sp;
+    V3 o, d;
+    int depth;
     HitInfo info;
-    int shader = -1;
-    C3 ret = c3(0, 0, 0);
-    enum { TRACE, SHADE, RET, RESUME } mode = TRACE;
-    bool done = false;
-    C3 result = c3(0, 0, 0);
-    // The lanes of a wave walk different trees, so left alone they drift out of phase and the two expensive steps -- the closest-hit
-    // search (TRACE) and the direct-light loop with its visible() queries (SHADE of a Lambert / Phong surface) -- would each run for
-    // the few lanes that happen to stand there.  Every round therefore first lets ALL lanes take their cheap steps (returns, loop
-    // heads of glossy / layered activations, pushes of recursive shaders) until each stands at a TRACE, at a direct SHADE or at the
-    // end; then one TRACE for all, then one direct SHADE for all.  A lane's own sequence of steps is unchanged.
-    for (;;) {
-        for (;;) {
-            const bool cheap = !done && (mode == RET || mode == RESUME || (mode == SHADE && S.shaders[shader].kind >= 3));
-            if (!__any(cheap)) break;
-            if (!cheap) continue;
-            if (mode == SHADE) {                               // shader->shade(ray, info) of a recursive shader: push its activation
-                const FRAY_RO DShader& sh = S.shaders[shader];
-                const int kind = sh.kind;
-                if (sp >= FRAY_WSTACK) { overflow = true; done = true; continue; }
-                WFrame& f = stack[sp];
-                f.shader = shader; f.i = 0; f.count = 0; f.o = o; f.d = d; f.depth = depth; f.info = info;
-                f.acc = c3(0, 0, 0); f.opacity = c3(0, 0, 0);
-                if (kind == 3) {                               // Reflection::shade
-                    V3 n = faceforward(d, info.norm);
-                    if (sh.glossiness == 1.0) {
-                        f.kind = WF_MULT; f.acc = ldc(sh.mult); sp++;
-                        o = info.ip + n * 1e-6;
-                        d = reflect(f.d, n);
-                        depth = depth + 1;
-                        mode = TRACE;
-                    } else {
-                        f.kind = WF_GLOSSY;
-                        f.count = depth == 0 ? sh.numSamples : 3;  // LOW_GLOSSY_SAMPLES, constants.h:36
-                        sp++;
-                        mode = RESUME;
-                    }
-                    continue;
-                }
-                if (kind == 4) {                               // Refraction::shade
-                    V3 n = faceforward(d, info.norm);
-                    double myIor = dot(n, info.norm) > 0 ? 1.0 / sh.ior : sh.ior / 1.0;
-                    V3 refr = refract(d, n, myIor);
-                    if (refr.x == 0 && refr.y == 0 && refr.z == 0) { ret = c3(0, 0, 0); mode = RET; continue; }
-                    f.kind = WF_MULT; f.acc = ldc(sh.mult); sp++;
-                    o = info.ip - n * 1e-6;
-                    d = refr;
-                    depth = depth + 1;
-                    mode = TRACE;
-                    continue;
-                }
-                f.kind = WF_LAYERED;                           // Layered::shade
-                sp++;
-                mode = RESUME;
-                continue;
+    int shader;
+    C3 ret;
+    int mode;
+};
+
+FD void wl_start(WhittedLane& L, V3 o, V3 d)
+{
+    L.sp = 0; L.o = o; L.d = d; L.depth = 0; L.shader = -1; L.ret = c3(0, 0, 0); L.mode = WM_TRACE;
+}
+// is the lane at a step that needs no search and no light loop?
+FD bool wl_cheap(const DScene& S, const WhittedLane& L)
+{
+    return L.mode == WM_RET || L.mode == WM_RESUME || (L.mode == WM_SHADE && S.shaders[L.shader].kind >= 3);
+}
+
+template <int ST, class G>
+FD void wl_cheap_step(const DScene& S, WhittedLane& L, G& tab, Cnt& c, bool& overflow)
+{
+    if (L.mode == WM_SHADE) {                              // shader->shade(ray, info) of a recursive shader: push its activation
+        const FRAY_RO DShader& sh = S.shaders[L.shader];
+        const int kind = sh.kind;
+        if (L.sp >= FRAY_WSTACK) { overflow = true; L.sp = 0; L.ret = c3(0, 0, 0); L.mode = WM_ROOT_RET; return; }
+        WFrame& f = L.stack[L.sp];
+        f.shader = L.shader; f.i = 0; f.count = 0; f.o = L.o; f.d = L.d; f.depth = L.depth; f.info = L.info;
+        f.acc = c3(0, 0, 0); f.opacity = c3(0, 0, 0);
+        if (kind == 3) {                                   // Reflection::shade
+            V3 n = faceforward(L.d, L.info.norm);
+            if (sh.glossiness == 1.0) {
+                f.kind = WF_MULT; f.acc = ldc(sh.mult); L.sp++;
+                L.o = L.info.ip + n * 1e-6;
+                L.d = reflect(f.d, n);
+                L.depth = L.depth + 1;
+                L.mode = WM_TRACE;
+            } else {
+                f.kind = WF_GLOSSY;
+                f.count = L.depth == 0 ? sh.numSamples : 3;    // LOW_GLOSSY_SAMPLES, constants.h:36
+                L.sp++;
+                L.mode = WM_RESUME;
             }
-            if (mode == RET) {                                 // a call returned `ret`
-                if (sp == 0) { result = ret; done = true; continue; }
-                WFrame& f = stack[sp - 1];
-                if (f.kind == WF_MULT) { ret = ret * f.acc; sp--; continue; }
-                if (f.kind == WF_GLOSSY) {
-                    f.acc = f.acc + ret * ldc(S.shaders[f.shader].mult);
-                    f.i++;
-                } else {
-                    f.acc = ret * f.opacity + (c3(1, 1, 1) - f.opacity) * f.acc;
-                    f.i++;
-                }
-                mode = RESUME;
-                continue;
-            }
-            // RESUME: continue the loop of the activation on top of the stack
-            WFrame& f = stack[sp - 1];
-            const FRAY_RO DShader& sh = S.shaders[f.shader];
-            if (f.kind == WF_GLOSSY) {                         // shading.cpp:172-204
-                if (f.i == f.count) { ret = f.acc / (float)f.count; sp--; mode = RET; continue; }
-                V3 n = faceforward(f.d, f.info.norm);
-                V3 b, cc;
-                orthonormalSystem(n, b, cc);
-                V3 reflected;
-                for (;;) {
-                    double x, y;
-                    rng_unit_disc(tab, x, y);
-                    x *= sh.deflectionScaling;
-                    y *= sh.deflectionScaling;
-                    V3 nn = normalized(n + b * x + cc * y);
-                    reflected = reflect(f.d, nn);
-                    if (dot(reflected, n) > 0) break;
-                }
-                o = f.info.ip + n * 1e-6;
-                d = reflected;
-                depth = f.depth + 1;
-                mode = TRACE;
-                continue;
-            }
-            // WF_LAYERED, shading.cpp:357-367
-            if (f.i == sh.layerCount) { ret = f.acc; sp--; mode = RET; continue; }
-            const FRAY_RO DLayer& L = S.layers[sh.layerBegin + f.i];
-            f.opacity = L.texture >= 0 ? texture_sample<ST>(S, L.texture, f.d, f.info, c) : ldc(L.opacity);
-            o = f.o; d = f.d; depth = f.depth; info = f.info;
-            shader = L.shader;
-            mode = SHADE;
+            return;
         }
-        if (!__any(!done)) break;
-        if (!done && mode == TRACE) {                          // raytrace(ray)
-            if (depth > S.maxTraceDepth) { ret = c3(0, 0, 0); mode = RET; }
-            else {
-                HitRec h;
-                closest_hit<ST>(S, o, d, h, c);
-                if (h.node <= -2) { ret = light_color(S.lights[-2 - h.node]); mode = RET; }
-                else if (h.node < 0) { ret = environment<ST>(S, d, c); mode = RET; }
-                else {
-                    const FRAY_RO DNode& N = S.nodes[h.node];
-                    shader = N.shader;
-                    finalize_hit<ST>(S, h, o, d, S.shaders[shader].usesUV || N.bumpTex >= 0, info);
-                    apply_bump<ST>(S, h.node, info, c);
-                    mode = SHADE;
-                }
-            }
+        if (kind == 4) {                                   // Refraction::shade
+            V3 n = faceforward(L.d, L.info.norm);
+            double myIor = dot(n, L.info.norm) > 0 ? 1.0 / sh.ior : sh.ior / 1.0;
+            V3 refr = refract(L.d, n, myIor);
+            if (refr.x == 0 && refr.y == 0 && refr.z == 0) { L.ret = c3(0, 0, 0); L.mode = WM_RET; return; }
+            f.kind = WF_MULT; f.acc = ldc(sh.mult); L.sp++;
+            L.o = L.info.ip - n * 1e-6;
+            L.d = refr;
+            L.depth = L.depth + 1;
+            L.mode = WM_TRACE;
+            return;
         }
-        if (!done && mode == SHADE && S.shaders[shader].kind <= 2) {   // Constant / Lambert / Phong ::shade
-            const FRAY_RO DShader& sh = S.shaders[shader];
-            const int kind = sh.kind;
-            if (kind == 0) ret = ldc(sh.color);
-            else ret = shade_direct<ST, G>(S, sh, d, info, tab, kind == 2, c);
-            mode = RET;
-        }
+        f.kind = WF_LAYERED;                               // Layered::shade
+        L.sp++;
+        L.mode = WM_RESUME;
+        return;
     }
-    return result;
+    if (L.mode == WM_RET) {                                // a call returned `ret`
+        if (L.sp == 0) { L.mode = WM_ROOT_RET; return; }
+        WFrame& f = L.stack[L.sp - 1];
+        if (f.kind == WF_MULT) { L.ret = L.ret * f.acc; L.sp--; return; }
+        if (f.kind == WF_GLOSSY) {
+            f.acc = f.acc + L.ret * ldc(S.shaders[f.shader].mult);
+            f.i++;
+        } else {
+            f.acc = L.ret * f.opacity + (c3(1, 1, 1) - f.opacity) * f.acc;
+            f.i++;
+        }
+        L.mode = WM_RESUME;
+        return;
+    }
+    // WM_RESUME: continue the loop of the activation on top of the stack
+    WFrame& f = L.stack[L.sp - 1];
+    const FRAY_RO DShader& sh = S.shaders[f.shader];
+    if (f.kind == WF_GLOSSY) {                             // shading.cpp:172-204
+        if (f.i == f.count) { L.ret = f.acc / (float)f.count; L.sp--; L.mode = WM_RET; return; }
+        V3 n = faceforward(f.d, f.info.norm);
+        V3 b, cc;
+        orthonormalSystem(n, b, cc);
+        V3 reflected;
+        for (;;) {
+            double x, y;
+            rng_unit_disc(tab, x, y);
+            x *= sh.deflectionScaling;
+            y *= sh.deflectionScaling;
+            V3 nn = normalized(n + b * x + cc * y);
+            reflected = reflect(f.d, nn);
+            if (dot(reflected, n) > 0) break;
+        }
+        L.o = f.info.ip + n * 1e-6;
+        L.d = reflected;
+        L.depth = f.depth + 1;
+        L.mode = WM_TRACE;
+        return;
+    }
+    // WF_LAYERED, shading.cpp:357-367
+    if (f.i == sh.layerCount) { L.ret = f.acc; L.sp--; L.mode = WM_RET; return; }
+    const FRAY_RO DLayer& Ly = S.layers[sh.layerBegin + f.i];
+    f.opacity = Ly.texture >= 0 ? texture_sample<ST>(S, Ly.texture, f.d, f.info, c) : ldc(Ly.opacity);
+    L.o = f.o; L.d = f.d; L.depth = f.depth; L.info = f.info;
+    L.shader = Ly.shader;
+    L.mode = WM_SHADE;
+}
+
+// raytrace(ray) up to the shader call (main.cpp:246-283), for a lane standing at WM_TRACE
+template <int ST>
+FD void wl_trace_step(const DScene& S, WhittedLane& L, Cnt& c)
+{
+    if (L.depth > S.maxTraceDepth) { L.ret = c3(0, 0, 0); L.mode = WM_RET; return; }
+    HitRec h;
+    closest_hit<ST>(S, L.o, L.d, h, c);
+    if (h.node <= -2) { L.ret = light_color(S.lights[-2 - h.node]); L.mode = WM_RET; }
+    else if (h.node < 0) { L.ret = environment<ST>(S, L.d, c); L.mode = WM_RET; }
+    else {
+        const FRAY_RO DNode& N = S.nodes[h.node];
+        L.shader = N.shader;
+        finalize_hit<ST>(S, h, L.o, L.d, S.shaders[L.shader].usesUV || N.bumpTex >= 0, L.info);
+        apply_bump<ST>(S, h.node, L.info, c);
+        L.mode = WM_SHADE;
+    }
+}
+
+// Constant / Lambert / Phong ::shade, for a lane standing at WM_SHADE of such a shader
+template <int ST, class G>
+FD void wl_direct_step(const DScene& S, WhittedLane& L, G& tab, Cnt& c)
+{
+    const FRAY_RO DShader& sh = S.shaders[L.shader];
+    const int kind = sh.kind;
+    if (kind == 0) L.ret = ldc(sh.color);
+    else L.ret = shade_direct<ST, G>(S, sh, L.d, L.info, tab, kind == 2, c);
+    L.mode = WM_RET;
 }

@@ -29,6 +29,12 @@
 #ifndef FRAY_WHITTED_WAVES
 #define FRAY_WHITTED_WAVES 3   // measured with persistent waves (boxed / forest DOF16 / zaphod ms): 2 -> 16.7 / 28.9 / 0.34, 3 -> 15.2 / 26.1 / 0.35, 4 -> 15.0 / 26.3 / 0.42, 5 -> 15.4 / 26.2 / 0.53
 #endif
+#ifndef FRAY_WHITTED_REFILL
+#define FRAY_WHITTED_REFILL 64  // idle lanes of a wave before they are handed new pixels (k_whitted); measured on dragon / smallpt Whitted: 1 -> 28.9 / 3.53 ms
+#endif
+#ifndef FRAY_MT_EARLY
+#define FRAY_MT_EARLY 160       // words drawn by one lane of a k_whitted wave at which the whole wave materialises its generator states
+#endif
 #ifndef FRAY_WH_SHADE_WAVES
 #define FRAY_WH_SHADE_WAVES 4   // the wavefront's closest-hit + shading kernel: 128 VGPRs, 9 spilled; forest DOF 16 24.1 -> 20.5 ms against 3 waves (168 VGPRs)
 #endif
@@ -218,8 +224,11 @@ static __global__ __launch_bounds__(256, FRAY_PRIMARY_WAVES) void k_primary(Prim
 
 static __constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0, 0.6}, {0.6, 0.6}};   // main.cpp:55-61
 
-// Whitted, scenes with recursive shaders (Reflection / Refraction / Layered): raytrace() per pixel, samples in order, one lane walks
-// the whole shade() tree (dev_whitted.hpp).  Scenes without them take the wavefront path below (k_wh_shade ...).
+// Whitted, scenes with recursive shaders (Reflection / Refraction / Layered): raytrace() per camera sample, one lane walks the whole shade()
+// tree (dev_whitted.hpp).  Scenes without them take the wavefront path below (k_wh_shade ...).
+// Persistent waves with PER-LANE refill: a lane that has finished its pixel takes the next one from the wave's pool (64 work items claimed
+// at a time from the XCD-affine cursors), so a lane whose pixel shows a 25-sample glossy floor does not keep 63 finished lanes waiting -- every
+// round of the machine has a closest-hit search to run for (nearly) every lane until the frame's items are gone.
 struct WhittedArgs { DScene S; DCamera C; DFrame F; int nItems; float* rgb; uint32_t* mtWork; const uint32_t* x397; DStats* st; DCursors* cur; };
 template <int ST>
 static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(WhittedArgs A)
@@ -231,67 +240,145 @@ static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(Whit
     const int nItems = A.nItems;
     DCursors* const cur = A.cur;
     DStats* const st = A.st;
+    const uint32_t lane = threadIdx.x & 63u;
     __shared__ double rightRay[6][256];
-    for (int r = 0, item = claim_items(cur, nItems, r); item < nItems; item = claim_items(cur, nItems, r)) {
+    WhittedLane L;
+    L.mode = WM_NEXT_PIXEL; L.sp = 0;
+    // the lane's pixel and camera sample
+    int item = 0, x = 0, y = 0, i = 0, eye = 0;
+    C3 avg = c3(0, 0, 0), cl = c3(0, 0, 0);
+    bool ovf = false;
+    Mt rnd = tab.r;
+    // the wave's pool of claimed work items [poolNext, poolEnd) and the claim state (wave-uniform)
+    int poolNext = 0, poolEnd = 0, claimR = 0;
+#ifdef FRAY_STAMPS
+    stamp_begin();
+#endif
+    for (;;) {
         const FRAY_RO WhittedArgs* AP = kernel_args<WhittedArgs>();
         const DScene& S = KARG(WhittedArgs, AP, S);
         const DCamera& C = KARG(WhittedArgs, AP, C);
         const DFrame& F = KARG(WhittedArgs, AP, F);
-        float* const rgb = KARG(WhittedArgs, AP, rgb);
-        const uint32_t* const x397 = KARG(WhittedArgs, AP, x397);
-        int x, y;
-        if (!item_pixel(F, item, x, y)) continue;
-        const uint32_t p = (uint32_t)y * (uint32_t)F.W + (uint32_t)x;
-        C3 avg = c3(0, 0, 0);
-        bool ovf = false;
-        for (int i = 0; i < F.spp; i++) {
-            const uint32_t sd = sample_seed(F.seed, p, (uint32_t)i);
-            tab.reseed_with(sd, x397[(size_t)i * nItems + item]);
-            Mt rnd = tab.r;
-            float ox, oy;
-            if (F.jitter) { ox = rng_float(rnd); oy = rng_float(rnd); }
-            else { ox = (float)kAAOffsets[i][0]; oy = (float)kAAOffsets[i][1]; }
-            double fx = (double)((float)x + ox), fy = (double)((float)y + oy);   // int + float, main.cpp:359
-            const bool stereo = C.stereoSeparation > 0;
-            V3 o, d;
-            if (stereo) {                                     // raytraceSinglePixel, main.cpp:306-317: both rays first, then left, then right
-                V3 orr, dr;
-                if (C.dof) { dof_ray(C, fx, fy, tab, o, d, 1); dof_ray(C, fx, fy, tab, orr, dr, 2); }
-                else { screen_ray(C, fx, fy, o, d, 1); screen_ray(C, fx, fy, orr, dr, 2); }
-                // the right eye's ray waits in LDS (the thread's own slots) while the left eye's tree is walked
-                rightRay[0][threadIdx.x] = orr.x; rightRay[1][threadIdx.x] = orr.y; rightRay[2][threadIdx.x] = orr.z;
-                rightRay[3][threadIdx.x] = dr.x; rightRay[4][threadIdx.x] = dr.y; rightRay[5][threadIdx.x] = dr.z;
-                bump<ST>(c.samples, 2);
-            } else {
-                if (C.dof) dof_ray(C, fx, fy, tab, o, d); else screen_ray(C, fx, fy, o, d);
-                bump<ST>(c.samples);
+        const bool stereo = C.stereoSeparation > 0;
+        // ---- cheap steps, until every lane stands at a search, a direct-light loop, or has nothing left
+        for (;;) {
+            // Lanes that want a pixel wait until FRAY_WHITTED_REFILL of them do (or nobody has anything else to do): a wave keeps working on
+            // neighbouring pixels -- its rays walk the same parts of the KD-trees -- instead of filling every free lane at once with pixels from elsewhere
+            const unsigned long long need = __ballot(L.mode == WM_NEXT_PIXEL);
+            const unsigned long long busy = __ballot(L.mode != WM_NEXT_PIXEL && L.mode != WM_EXHAUSTED);
+            const bool refill = need && ((int)__popcll(need) >= FRAY_WHITTED_REFILL || !busy);
+            // a lane's generator is about to leave its 227-word register window: every lane of the wave that is inside a camera sample makes its
+            // full state now, together (MtLong::materialise)
+            if (__any(L.mode < WM_NEXT_SAMPLE && tab.idx < 0 && tab.r.j >= FRAY_MT_EARLY)) {
+                if (L.mode < WM_NEXT_SAMPLE && tab.idx < 0) tab.materialise();
             }
-            C3 cl = c3(0, 0, 0), cr = c3(0, 0, 0);
-            for (int eye = 0; eye < (stereo ? 2 : 1); eye++) {      // one copy of the integrator for both eyes
-                if (eye == 1) {
-                    o = v3(rightRay[0][threadIdx.x], rightRay[1][threadIdx.x], rightRay[2][threadIdx.x]);
-                    d = v3(rightRay[3][threadIdx.x], rightRay[4][threadIdx.x], rightRay[5][threadIdx.x]);
+            const bool cheap = L.mode == WM_NEXT_PIXEL ? refill : (L.mode == WM_ROOT_RET || L.mode == WM_NEXT_SAMPLE || (L.mode < WM_ROOT_RET && wl_cheap(S, L)));
+            if (!__any(cheap)) break;
+            // work items for the lanes that need a pixel: from the wave's pool, refilled one 8x8 tile at a time
+            if (refill) {
+                if (poolNext == poolEnd && claimR < 8) {
+#ifdef FRAY_STAMPS
+                    {   // diagnostic: how long did the tile this wave just finished take?  stamp[15] = the longest, stamp[14] = tiles over 1 ms (2.4 M cycles)
+                        static __shared__ unsigned long long tileT0[4];
+                        unsigned long long t;
+                        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+                        const int w = threadIdx.x >> 6;
+                        if (lane == 0) {
+                            if (poolEnd != 0) { const unsigned long long dur = t - tileT0[w]; atomicMax(&st->stamp[15], dur); if (dur > 2400000ull) atomicAdd(&st->stamp[14], 1ull); if (dur > 12000000ull) atomicAdd(&st->stamp[13], 1ull); }
+                            tileT0[w] = t;
+                        }
+                    }
+#endif
+                    const int first = claim_items(cur, nItems, claimR);       // this lane's item of the claimed tile; nItems on every lane when nothing is left
+                    int base = __builtin_amdgcn_readfirstlane(first - (int)lane);
+#ifdef FRAY_EXP_REVERSE
+                    if (base < nItems) base = nItems - 64 - base;
+#endif
+                    if (base < nItems) { poolNext = base; poolEnd = base + 64; }
                 }
-                const C3 v = raytrace_full<ST, MtLong>(S, o, d, tab, c, ovf);
-                if (eye == 0) cl = v; else cr = v;
-            }
-            if (stereo) {
-                if (S.saturation != 1) {                      // Color::adjustSaturation, color.h:127-133
-                    float ml = (cl.r + cl.g + cl.b) / 3.0f, mr = (cr.r + cr.g + cr.b) / 3.0f;
-                    cl = c3(ml + (cl.r - ml) * S.saturation, ml + (cl.g - ml) * S.saturation, ml + (cl.b - ml) * S.saturation);
-                    cr = c3(mr + (cr.r - mr) * S.saturation, mr + (cr.g - mr) * S.saturation, mr + (cr.b - mr) * S.saturation);
+                const int have = poolEnd - poolNext;
+                const int rank = (int)__popcll(need & ((1ull << lane) - 1ull));
+                if (L.mode == WM_NEXT_PIXEL) {
+                    if (rank < have) {
+                        item = poolNext + rank;
+                        if (item_pixel(F, item, x, y)) { i = 0; avg = c3(0, 0, 0); L.mode = WM_NEXT_SAMPLE; }
+                        // a slot of a ragged edge bucket outside the frame: nothing to render, ask again
+                    } else if (have == 0 && claimR >= 8) {
+                        L.mode = WM_EXHAUSTED;
+                    }
                 }
-                avg = avg + (cl * ldc(C.leftMask) + cr * ldc(C.rightMask));
-            } else {
-                avg = avg + cl;
+                const int want = (int)__popcll(need);
+                poolNext += want < have ? want : have;
             }
-            ovf = ovf || rnd.j > 227;
+            if (L.mode == WM_NEXT_SAMPLE) {
+                if (i == F.spp) {                                            // vfb[y][x] = sum / spp, main.cpp:360
+                    avg = avg / (float)F.spp;
+                    const size_t q = ((size_t)y * F.W + x) * 3;
+                    float* const rgb = KARG(WhittedArgs, AP, rgb);
+                    rgb[q] = avg.r; rgb[q + 1] = avg.g; rgb[q + 2] = avg.b;
+                    L.mode = WM_NEXT_PIXEL;
+                } else {
+                    const uint32_t* const x397 = KARG(WhittedArgs, AP, x397);
+                    const uint32_t p = (uint32_t)y * (uint32_t)F.W + (uint32_t)x;
+                    tab.reseed_with(sample_seed(F.seed, p, (uint32_t)i), x397[(size_t)i * nItems + item]);
+                    rnd = tab.r;
+                    float ox, oy;
+                    if (F.jitter) { ox = rng_float(rnd); oy = rng_float(rnd); }
+                    else { ox = (float)kAAOffsets[i][0]; oy = (float)kAAOffsets[i][1]; }
+                    const double fx = (double)((float)x + ox), fy = (double)((float)y + oy);   // int + float, main.cpp:359
+                    V3 o, d;
+                    if (stereo) {                                             // raytraceSinglePixel, main.cpp:306-317: both rays first, then left, then right
+                        V3 orr, dr;
+                        if (C.dof) { dof_ray(C, fx, fy, tab, o, d, 1); dof_ray(C, fx, fy, tab, orr, dr, 2); }
+                        else { screen_ray(C, fx, fy, o, d, 1); screen_ray(C, fx, fy, orr, dr, 2); }
+                        // the right eye's ray waits in LDS (the thread's own slots) while the left eye's tree is walked
+                        rightRay[0][threadIdx.x] = orr.x; rightRay[1][threadIdx.x] = orr.y; rightRay[2][threadIdx.x] = orr.z;
+                        rightRay[3][threadIdx.x] = dr.x; rightRay[4][threadIdx.x] = dr.y; rightRay[5][threadIdx.x] = dr.z;
+                        bump<ST>(c.samples, 2);
+                    } else {
+                        if (C.dof) dof_ray(C, fx, fy, tab, o, d); else screen_ray(C, fx, fy, o, d);
+                        bump<ST>(c.samples);
+                    }
+                    eye = 0;
+                    wl_start(L, o, d);
+                }
+            } else if (L.mode == WM_ROOT_RET) {                              // the camera ray's raytrace() returned
+                if (stereo && eye == 0) {
+                    cl = L.ret;
+                    eye = 1;
+                    wl_start(L, v3(rightRay[0][threadIdx.x], rightRay[1][threadIdx.x], rightRay[2][threadIdx.x]),
+                             v3(rightRay[3][threadIdx.x], rightRay[4][threadIdx.x], rightRay[5][threadIdx.x]));
+                } else {
+                    if (stereo) {
+                        C3 cr = L.ret;
+                        if (S.saturation != 1) {                              // Color::adjustSaturation, color.h:127-133
+                            float ml = (cl.r + cl.g + cl.b) / 3.0f, mr = (cr.r + cr.g + cr.b) / 3.0f;
+                            cl = c3(ml + (cl.r - ml) * S.saturation, ml + (cl.g - ml) * S.saturation, ml + (cl.b - ml) * S.saturation);
+                            cr = c3(mr + (cr.r - mr) * S.saturation, mr + (cr.g - mr) * S.saturation, mr + (cr.b - mr) * S.saturation);
+                        }
+                        avg = avg + (cl * ldc(C.leftMask) + cr * ldc(C.rightMask));
+                    } else {
+                        avg = avg + L.ret;
+                    }
+                    ovf = ovf || rnd.j > 227;
+                    i++;
+                    L.mode = WM_NEXT_SAMPLE;
+                }
+            } else if (L.mode < WM_ROOT_RET && wl_cheap(S, L)) {
+                wl_cheap_step<ST, MtLong>(S, L, tab, c, ovf);
+            }
         }
-        avg = avg / (float)F.spp;
-        if (ovf) atomicAdd(&st->rngOverflow, 1ull);
-        size_t q = (size_t)p * 3;
-        rgb[q] = avg.r; rgb[q + 1] = avg.g; rgb[q + 2] = avg.b;
+        STAMP(12);
+        if (!__any(L.mode != WM_EXHAUSTED)) break;
+        if (L.mode == WM_TRACE) wl_trace_step<ST>(S, L, c);
+        STAMP(14);
+        if (L.mode == WM_SHADE && S.shaders[L.shader].kind <= 2) wl_direct_step<ST, MtLong>(S, L, tab, c);
+        STAMP(10);
     }
+#ifdef FRAY_STAMPS
+    if (lane < 16) atomicAdd(&st->stamp[lane], g_stampAcc[threadIdx.x >> 6][lane]);
+#endif
+    if (ovf) atomicAdd(&st->rngOverflow, 1ull);
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
@@ -587,13 +674,14 @@ FD uint32_t seg_first(const FRAY_RO uint32_t* off, uint32_t nSeg, uint32_t begin
     }
     return lo;
 }
+FD uint32_t run_slot(uint32_t run, uint32_t chunk, uint32_t e) { return (run >> 1) * chunk + ((run & 1u) ? chunk - 1u - e : e); }
 FD uint32_t seg_map(const FRAY_RO uint32_t* off, uint32_t nSeg, uint32_t chunk, uint32_t base, uint32_t di, bool live, uint32_t& seg)
 {
     while (seg + 1 < nSeg && off[seg + 1] <= base) seg++;
     uint32_t i = 0, s = seg, lo = off[s];
-    for (;;) {                        // the segments that overlap this batch: one, now and then two
+    for (;;) {                        // the runs that overlap this batch: one, now and then two
         const uint32_t hi = off[s + 1];
-        if (live && di >= lo && di < hi) i = s * chunk + (di - lo);
+        if (live && di >= lo && di < hi) i = run_slot(s, chunk, di - lo);
         if (hi >= base + 64u || s + 1 >= nSeg) break;
         s++;
         lo = hi;
@@ -690,13 +778,63 @@ FD WaveShare wave_share(uint32_t n)
     return r;
 }
 
+// Which end of its wave's queue segment a ray goes to (QMeta, dev_queues.hpp): true = it may enter one of the scene's gates (DGate: the boxes
+// of the meshes with long brute-force triangle loops).  A slab test in FP32 on the world-space box -- a scheduling hint, nothing else.
+FD bool ray_gate_class(const DScene& S, V3 o, V3 d)
+{
+    const int ng = S.nGates;
+    if (ng == 0) return false;
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    const float rx = __builtin_amdgcn_rcpf((float)d.x), ry = __builtin_amdgcn_rcpf((float)d.y), rz = __builtin_amdgcn_rcpf((float)d.z);
+    bool any = false;
+    for (int g = 0; g < ng; g++) {
+        const FRAY_RO DGate& G = S.gates[g];
+        const float ax = ((float)G.lo[0] - ox) * rx, bx = ((float)G.hi[0] - ox) * rx;
+        const float ay = ((float)G.lo[1] - oy) * ry, by = ((float)G.hi[1] - oy) * ry;
+        const float az = ((float)G.lo[2] - oz) * rz, bz = ((float)G.hi[2] - oz) * rz;
+        const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+        const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        any = any || !(t0 > t1 * 1.0001f + 1e-3f);          // NaNs (a direction component of 0 on a box face) count as "may enter"
+    }
+    return any;
+}
+
+// Where the lanes of one batch of 64 append to a wave's queue segment: the gate-free rays at the front (in order), the others at the back (in
+// reverse), ranked by ballot -- no global counter.  `nF` / `nB`: entries so far at either end (wave-uniform).
+struct SegEnds { uint32_t begin, chunk, nF, nB; };
+// The same for appends made deep inside divergent code (the next-event segment is written where path_shade samples it, so that its fifteen
+// registers are not carried to the end of the iteration): there the lanes of a batch may pass the append in several groups, so a ballot rank is not
+// safe (two groups would both count from zero: measured -- 2 % of the segments of the instrumented kernel variant overwrote each other).  The
+// wave's two counters live in LDS and every appending lane takes its own slot with an LDS atomic; the order inside the segment is then
+// arbitrary, which changes nothing (every path carries its own sample slot).
+struct SegEndsShared { uint32_t begin, chunk; uint32_t* n; };        // n[0] front count, n[1] back count: this wave's pair in LDS
+FD uint32_t seg_take(const SegEndsShared& E, bool back)
+{
+    const uint32_t k = atomicAdd(E.n + (back ? 1 : 0), 1u);
+    return back ? E.begin + E.chunk - 1u - k : E.begin + k;
+}
+// the slot of a lane that appends (callable where only the appending lanes of the batch are active: the counts are not touched) ...
+FD uint32_t seg_slot(const SegEnds& E, bool put, bool back)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long mF = __ballot(put && !back), mB = __ballot(put && back);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    return back ? E.begin + E.chunk - 1u - (E.nB + (uint32_t)__popcll(mB & below)) : E.begin + E.nF + (uint32_t)__popcll(mF & below);
+}
+// ... and the counts, advanced once per batch where the whole wave is together again
+FD void seg_advance(SegEnds& E, bool put, bool back)
+{
+    E.nF += (uint32_t)__popcll(__ballot(put && !back));
+    E.nB += (uint32_t)__popcll(__ballot(put && back));
+}
+
 // What pathtrace() does with a path once its closest hit is known (main.cpp:201-242): light / environment hits end
 // it; otherwise bump, the discarded spawnRay, the next-event sample (everything but its visibility query -> `shadow`
 // segment sa -> sb carrying sc), the real spawnRay, the throughput update and the entry test of the next iteration
 // (`cont`: ps is the path to continue).
 template <int ST, bool BARY, class G>
-FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitRec& h, const TermBuf& TB, DStats* st, const StereoBuf& SB, bool& cont, bool& shadow,
-                   const ShadowQueue& SQ, uint32_t shadowBase, Cnt& c)
+FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitRec& h, const TermBuf& TB, DStats* st, const StereoBuf& SB, bool& cont, bool& shadow, bool& shadowBack,
+                   const ShadowQueue& SQ, const SegEndsShared& shadowEnds, Cnt& c)
 {
     C3 own = c3(0, 0, 0);          // this bounce's term, unless a queued next-event segment will provide it
     if (h.node <= -2) {                                       // main.cpp:201-208
@@ -714,13 +852,13 @@ FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitRec& h, const Te
         mt_skip(ps.tab, spawn_words(sh));                     // the discarded spawnRay (main.cpp:219-224)
         {
             // the next-event segment goes to the wave's shadow segment right here (ballot rank among the lanes that sampled a light), so
-            // that it is not carried in registers across the spawn; the wave's count is advanced by the caller (bounce_emit)
+            // that it is not carried in registers across the spawn
             V3 sa, sb;
             C3 sc;
             shadow = nee_prepare(S, ps.d, info, ps.pm, sh, ps.rnd, ps.tab, sa, sb, sc);
-            const unsigned long long smask = __ballot(shadow);
             if (shadow) {
-                const uint32_t j = shadowBase + (uint32_t)__popcll(smask & ((1ull << (threadIdx.x & 63u)) - 1ull));
+                shadowBack = ray_gate_class(S, sa, sb - sa);
+                const uint32_t j = seg_take(shadowEnds, shadowBack);
                 SQ.ax[j] = sa.x; SQ.ay[j] = sa.y; SQ.az[j] = sa.z;
                 SQ.bx[j] = sb.x; SQ.by[j] = sb.y; SQ.bz[j] = sb.z;
                 SQ.cr[j] = sc.r; SQ.cg[j] = sc.g; SQ.cb[j] = sc.b;
@@ -745,18 +883,6 @@ FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitRec& h, const Te
     if (!shadow) term_store(TB, ps.slot, own);
 }
 
-// Survivors and next-event segments of one batch of 64 paths go to the wave's own segments of the output queues
-// (ballot rank, no global counter).
-template <class G>
-FD void bounce_emit(const PathQueue& Qout, uint32_t segBegin, uint32_t& produced, uint32_t& producedS, bool cont, bool shadow, const PathStateT<G>& ps)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long mask = __ballot(cont);
-    if (cont) path_store(Qout, segBegin + produced + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), ps);
-    produced += (uint32_t)__popcll(mask);
-    producedS += (uint32_t)__popcll(__ballot(shadow));       // the segments themselves were written by path_shade
-}
-
 // **Dominant kernel**: one pathtrace() iteration (main.cpp:171-244) for every live path of the queue: closest hit,
 // then path_shade.  Every wave owns a contiguous share of the queue's dense indices and writes its survivors and
 // next-event segments into its own segments of the output queues.
@@ -777,7 +903,10 @@ static __global__ __launch_bounds__(256, kd_variant(ST) ? FRAY_BOUNCE_WAVES : FR
     const uint32_t nSeg = metaIn.p->nSeg, chunkIn = metaIn.p->chunk;
     const WaveShare ws = wave_share(metaIn.p->n);
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t produced = 0, producedS = 0;                         // wave-uniform
+    SegEnds outEnds{ws.begin, ws.chunk, 0, 0};                                            // wave-uniform
+    __shared__ uint32_t shadowCount[4][2];
+    if (lane < 2) shadowCount[threadIdx.x >> 6][lane] = 0;
+    const SegEndsShared shadowEnds{ws.begin, ws.chunk, shadowCount[threadIdx.x >> 6]};
     uint32_t seg = ws.begin < ws.end ? seg_first(off, nSeg, ws.begin) : 0;
 #ifdef FRAY_STAMPS
     stamp_begin();
@@ -792,7 +921,7 @@ static __global__ __launch_bounds__(256, kd_variant(ST) ? FRAY_BOUNCE_WAVES : FR
         const StereoBuf& SB = KARG(BounceArgs, AP, SB);
         const LongRng& LR = KARG(BounceArgs, AP, LR);
         const uint32_t di = base + lane;
-        bool cont = false, shadow = false;
+        bool cont = false, shadow = false, shadowBack = false;
         PathStateT<G> ps;
         bool live = di < ws.end;
         const uint32_t i = seg_map(off, nSeg, chunkIn, base, di, live, seg);
@@ -804,6 +933,11 @@ static __global__ __launch_bounds__(256, kd_variant(ST) ? FRAY_BOUNCE_WAVES : FR
             HitRec h;
             closest_hit<ST>(S, ps.o, ps.d, h, c);
             path_load_rest(Qin, i, ps);
+#ifdef FRAY_QCHECK
+            // diagnostic build: a queue entry that no producer wrote (or that was consumed before) is counted and dropped
+            if (ps.slot >= TB.nPaths) { atomicAdd(&st->rngOverflow, 1ull << 32); ps.slot = 0; ps.pm = c3(0, 0, 0); ps.depth = 0x7fff; }
+            else Qin.slot[i] = 0xffffffffu;
+#endif
             if constexpr (LONG) {
                 int px, py;
                 item_pixel(LR.F, (int)(ps.slot % (uint32_t)LR.nItems), px, py);
@@ -814,17 +948,25 @@ static __global__ __launch_bounds__(256, kd_variant(ST) ? FRAY_BOUNCE_WAVES : FR
                 ps.tab.col = LR.cols + (size_t)624 * LR.nPaths + ps.slot;
             }
             STAMP(8);
-            path_shade<ST, false>(S, ps, h, TB, st, SB, cont, shadow, SQ, ws.begin + producedS, c);
+            path_shade<ST, false>(S, ps, h, TB, st, SB, cont, shadow, shadowBack, SQ, shadowEnds, c);
             STAMP(10);
         }
-        bounce_emit(Qout, ws.begin, produced, producedS, cont, shadow, ps);
+        // survivors and next-event segments of this batch of 64 paths go to the wave's own segments of the output queues: gate-free rays to
+        // the front, the others to the back (ballot ranks, no global counter)
+        const bool back = cont && ray_gate_class(S, ps.o, ps.d);
+        const uint32_t slotOut = seg_slot(outEnds, cont, back);
+        if (cont) path_store(Qout, slotOut, ps);
+        seg_advance(outEnds, cont, back);
         STAMP(13);
     }
 #ifdef FRAY_STAMPS
     if (lane < 16) atomicAdd(&st->stamp[lane], g_stampAcc[threadIdx.x >> 6][lane]);
 #endif
-    if (lane == 0) { metaOut->cnt[ws.w] = produced; metaShadow->cnt[ws.w] = producedS; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { metaOut->chunk = ws.chunk; metaOut->nSeg = ws.W; metaShadow->chunk = ws.chunk; metaShadow->nSeg = ws.W; }
+    if (lane == 0) {
+        metaOut->cnt[2 * ws.w] = outEnds.nF; metaOut->cnt[2 * ws.w + 1] = outEnds.nB;
+        metaShadow->cnt[2 * ws.w] = shadowCount[threadIdx.x >> 6][0]; metaShadow->cnt[2 * ws.w + 1] = shadowCount[threadIdx.x >> 6][1];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { metaOut->chunk = ws.chunk; metaOut->nSeg = 2 * ws.W; metaShadow->chunk = ws.chunk; metaShadow->nSeg = 2 * ws.W; }
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
@@ -859,7 +1001,14 @@ static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(Sha
             const V3 a = v3(SQ.ax[i], SQ.ay[i], SQ.az[i]), b = v3(SQ.bx[i], SQ.by[i], SQ.bz[i]);
             STAMP(0);
             const bool vis = visible<ST>(S, a, b, c);
-            term_store(TB, SQ.slot[i], vis ? c3(SQ.cr[i], SQ.cg[i], SQ.cb[i]) : c3(0, 0, 0));
+            const uint32_t sl = SQ.slot[i];
+#ifdef FRAY_QCHECK
+            // diagnostic build: an entry whose slot is not a slot of this batch was never written by the bounce kernel (or was consumed before): count it
+            // (the frame then fails with E_UNSUPPORTED), do not store; consumed entries are poisoned
+            if (sl >= TB.nPaths) { atomicAdd(&st->rngOverflow, 1ull); continue; }
+            SQ.slot[i] = 0xffffffffu;
+#endif
+            term_store(TB, sl, vis ? c3(SQ.cr[i], SQ.cg[i], SQ.cb[i]) : c3(0, 0, 0));
         }
         STAMP(13);
     }

@@ -296,16 +296,20 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     {
         static const char* names[16] = {"queue lookup + ray load / camera ray", "local ray (transform)", "root box test", "tree-less triangle loop", "KD walk: child tests", "other geometry (plane / sphere / KD leaf accept)",
                                         "node result + world distance", "lights", "load rest of path", "KD walk: climbs", "shading (finalize .. spawn / light loops)", "KD leaves: triangle tests",
-                                        "-", "queue stores / loop overhead", "-", "-"};
+                                        "k_whitted: cheap steps (returns, loop heads, pushes; pixel / sample set-up)", "queue stores / loop overhead", "k_whitted: rest of the trace step (attributes, bump)", "-"};
         for (int q = 0; q < 2; q++) {
             double tot = 0;
             for (int k = 0; k < 16; k++) tot += (double)dsv[q].stamp[k];
             fprintf(stderr, "[stamps] %s: total %.4g wave-cycles\n", q == 0 ? "closest-hit kernel (k_pt_bounce / k_primary / k_wh_shade)" : "any-hit kernel (k_pt_shadow / k_wh_visible)", tot);
-            for (int k = 0; k < 16; k++) if (dsv[q].stamp[k]) fprintf(stderr, "[stamps]   %-36s %6.2f %%\n", names[k], 100.0 * (double)dsv[q].stamp[k] / tot);
+            for (int k = 0; k < 16; k++) if (dsv[q].stamp[k]) fprintf(stderr, "[stamps]   %-36s %6.2f %%   (%llu)\n", names[k], 100.0 * (double)dsv[q].stamp[k] / tot, (unsigned long long)dsv[q].stamp[k]);
         }
     }
 #endif
     if (dsv[0].rngOverflow || dsv[1].rngOverflow) {
+#ifdef FRAY_QCHECK
+        fprintf(stderr, "[qcheck] bounce kernel: %llu stale path entries, %llu other events; shadow kernel: %llu stale segments\n", (unsigned long long)(dsv[0].rngOverflow >> 32),
+                (unsigned long long)(dsv[0].rngOverflow & 0xffffffffull), (unsigned long long)dsv[1].rngOverflow);
+#endif
         set_error("frayhip_render: a camera sample left the supported envelope (Whitted: shade() nesting deeper than 40, or a camera sample whose pixel jitter stream passed 227 words)");
         return FRAYHIP_E_UNSUPPORTED;
     }

@@ -86,7 +86,7 @@ def test_whitted_colour_vs_oracle(fray, abi, oracle, gpu, scene, W, H, over):
     assert np.all(rms(img, ref) <= RMS_TOL), rms(img, ref)
     same = float((img == ref).all(axis=2).mean())      # beyond the tolerance: the reference's evaluation order + correctly rounded trig
     print("%s %s: %.2f %% of the pixels bit-identical to the oracle" % (scene, over, 100 * same))
-    assert same >= 0.995, same
+    assert same == 1.0, same                           # every Whitted case is the oracle's picture bit for bit; anything less is a regression
     img2, st = s.render(seed=42, stats=True)
     assert np.array_equal(img, img2)                   # instrumented kernels: same image
     for k in COUNTERS:
@@ -123,14 +123,18 @@ def test_path_traced_colour_vs_oracle(fray, abi, oracle, gpu, scene, W, H, over)
     # last-place difference of a direction flips a branch
     same = float((img == ref).all(axis=2).mean())
     print("%s %s: %.2f %% of the pixels bit-identical to the oracle" % (scene, over, 100 * same))
-    assert same >= 0.995, same
+    assert same == 1.0, same                           # all eight cases, at this seed: a drop to 99.9 % is a regression, not noise
     eyes = 2 if s.camera.stereoSeparation > 0 else 1
     assert st["samples"] == ost["samples"] == W * H * s.samples_per_pixel() * eyes
-    # libm differs in the last ulp between glibc and ocml, so secondary rays may differ in the last
-    # bits and a few of them take another branch: ray counts agree to 1e-4, not exactly
+    # The device's sin / cos / acos are correctly rounded, glibc's are in 99.85 % of calls: a direction may differ in its last place without
+    # changing any hit.  Rays, node tests, KD visits and leaf references are the oracle's exactly; only the count of triangle tests moves by a
+    # few per million (a box test at an edge going the other way)
     print("   work counters GPU - oracle:", {k: int(st[k]) - int(ost[k]) for k in COUNTERS})
-    for k in ("closest_rays", "shadow_rays", "node_tests"):
-        assert abs(st[k] - ost[k]) <= 1e-4 * ost[k] + 2, k
+    for k in COUNTERS:
+        if k == "tri_tests":
+            assert abs(st[k] - ost[k]) <= 2e-5 * ost[k] + 2, k
+        else:
+            assert st[k] == ost[k], k
     s.close()
 
 
@@ -229,8 +233,9 @@ def test_whitted_layered_glossy_refraction_recursion_vs_oracle(fray, abi, oracle
     assert np.all(rms(img, ref) <= RMS_TOL), rms(img, ref)
     for k in ("samples",):
         assert st[k] == ost[k]
-    for k in ("closest_rays", "shadow_rays", "node_tests"):        # libm ulps may flip a rejection-sampled draw
-        assert abs(st[k] - ost[k]) <= 1e-3 * ost[k] + 2, k
+    print("   work counters GPU - oracle:", {k: int(st[k]) - int(ost[k]) for k in ("closest_rays", "shadow_rays", "node_tests", "tri_tests")})
+    for k in ("closest_rays", "shadow_rays", "node_tests"):
+        assert st[k] == ost[k], k
     s.close()
 
 
@@ -519,14 +524,14 @@ def test_gpu_colour_vs_reference_fixture(fray, gpu, path):
         diff = np.abs(img.astype(np.float64) - z["image"])
         bad = (diff > 1e-5).any(axis=2)
         print("ref_fuzz1009_pt: %d of %d pixels differ from the reference fixture" % (int(bad.sum()), bad.size))
-        assert bad.sum() <= 2 and np.sqrt((diff[~bad] ** 2).mean()) <= 1e-6, int(bad.sum())
+        assert bad.sum() == 0 and np.array_equal(img, z["image"]), int(bad.sum())     # since the device's own trig (round 2): every pixel
         s.close()
         return
     assert np.all(rms(img, z["image"]) <= RMS_TOL), rms(img, z["image"])
     # and beyond: the fixture is the output of the reference's own shader / light / camera / geometry object code
     same = float((img == z["image"]).all(axis=2).mean())
     print("%s: %.2f %% of the pixels bit-identical to the reference fixture" % (os.path.basename(path), 100 * same))
-    assert same >= 0.995, same
+    assert same == 1.0, same
     s.close()
 
 

@@ -34,6 +34,7 @@ WORKLOADS = {
     "forest_primary": ("forest.fray", 1920, 1080, dict(wantAA=0, interactive=0), "forest.fray 1920x1080 primary rays (closest hit only)"),
     "boxed_primary": ("boxed.fray", 1920, 1080, dict(wantAA=0), "boxed.fray 1920x1080 primary rays (closest hit only)"),
     "smallpt_whitted": ("smallpt.fray", 1920, 1080, dict(gi=0, wantAA=0), "smallpt.fray 1920x1080 1spp Whitted (mirror + glass recursion: k_whitted)"),
+    "bokeh_dof": ("hw10/bokeh.fray", 640, 480, dict(), "hw10/bokeh.fray 640x480 DOF 45spp Whitted as shipped (Cube - Cube CSG floor, Layered over a mirror, Phong mesh: k_whitted, CSG variant)"),
     "dragon_whitted": ("hw9/dragon.fray", 1920, 1080, dict(wantAA=0), "hw9/dragon.fray 1920x1080 1spp Whitted (glossy floor: k_whitted)"),
 }
 

@@ -32,6 +32,11 @@
 #ifndef FRAY_WHITTED_REFILL
 #define FRAY_WHITTED_REFILL 64  // idle lanes of a wave before they are handed new pixels (k_whitted); measured on dragon / smallpt Whitted: 1 -> 28.9 / 3.53 ms
 #endif
+#ifndef FRAY_CSG_WAVES
+#define FRAY_CSG_WAVES 8        // the Cube / CSG kernel variants (flag bit 1): the hit lists' sorting code wants registers more than the chip wants waves
+#endif
+// waves per SIMD a kernel is register-allocated for: `n` for the common variants, FRAY_CSG_WAVES for the Cube / CSG ones
+constexpr int waves_for(int st, int n) { return (st & 2) ? (FRAY_CSG_WAVES < n ? FRAY_CSG_WAVES : n) : n; }
 #ifndef FRAY_MT_EARLY
 #define FRAY_MT_EARLY 160       // words drawn by one lane of a k_whitted wave at which the whole wave materialises its generator states
 #endif
@@ -188,7 +193,7 @@ static __global__ __launch_bounds__(256) void k_seed(DFrame F, int nItems, int s
 // ---- MODE_PRIMARY_ID ------------------------------------------------------------------------------
 struct PrimaryArgs { DScene S; DCamera C; DFrame F; int nItems; int32_t* hitId; double* hitDist; DStats* st; DCursors* cur; };
 template <int ST>
-static __global__ __launch_bounds__(256, FRAY_PRIMARY_WAVES) void k_primary(PrimaryArgs A)
+static __global__ __launch_bounds__(256, waves_for(ST, FRAY_PRIMARY_WAVES)) void k_primary(PrimaryArgs A)
 {
     Cnt c = zero_cnt();
     const int nItems = A.nItems;
@@ -231,7 +236,7 @@ static __constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0,
 // round of the machine has a closest-hit search to run for (nearly) every lane until the frame's items are gone.
 struct WhittedArgs { DScene S; DCamera C; DFrame F; int nItems; float* rgb; uint32_t* mtWork; const uint32_t* x397; DStats* st; DCursors* cur; };
 template <int ST>
-static __global__ __launch_bounds__(256, FRAY_WHITTED_WAVES) void k_whitted(WhittedArgs A)
+static __global__ __launch_bounds__(256, waves_for(ST, FRAY_WHITTED_WAVES)) void k_whitted(WhittedArgs A)
 {
     Cnt c = zero_cnt();
     MtLong tab;
@@ -450,7 +455,7 @@ FD void wh_shade_eye(const DScene& S, V3 o, V3 d, MtLong& tab, const WhittedQueu
 
 struct WhShadeArgs { DScene S; DCamera C; DFrame F; int nItems, s0, chunk; WhittedQueue Q; uint32_t* mtWork; const uint32_t* x397; DStats* st; };
 template <int ST>
-static __global__ __launch_bounds__(256, FRAY_WH_SHADE_WAVES) void k_wh_shade(WhShadeArgs A)
+static __global__ __launch_bounds__(256, waves_for(ST, FRAY_WH_SHADE_WAVES)) void k_wh_shade(WhShadeArgs A)
 {
     Cnt c = zero_cnt();
     MtLong tab;
@@ -526,7 +531,7 @@ static __global__ __launch_bounds__(256, FRAY_WH_SHADE_WAVES) void k_wh_shade(Wh
 
 struct WhVisibleArgs { DScene S; WhittedQueue Q; size_t N; int T; DStats* st; };
 template <int ST>
-static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_wh_visible(WhVisibleArgs A)
+static __global__ __launch_bounds__(256, waves_for(ST, FRAY_SHADOW_WAVES)) void k_wh_visible(WhVisibleArgs A)
 {
     Cnt c = zero_cnt();
     const size_t N = A.N;
@@ -891,7 +896,7 @@ FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitRec& h, const Te
 struct LongRng { uint32_t* cols; uint32_t nPaths; DFrame F; int nItems, s0; };
 struct BounceArgs { DScene S; PathQueue Qin, Qout; ShadowQueue SQ; QMetaRO metaIn; QMeta* metaOut; QMeta* metaShadow; TermBuf TB; StereoBuf SB; LongRng LR; DStats* st; };
 template <int ST, bool LONG>
-static __global__ __launch_bounds__(256, kd_variant(ST) ? FRAY_BOUNCE_WAVES : FRAY_BOUNCE_WAVES_NOKD) void k_pt_bounce(BounceArgs A)
+static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOUNCE_WAVES : FRAY_BOUNCE_WAVES_NOKD)) void k_pt_bounce(BounceArgs A)
 {
     typedef typename std::conditional<LONG, MtPath, Mt>::type G;
     Cnt c = zero_cnt();
@@ -975,7 +980,7 @@ static __global__ __launch_bounds__(256, kd_variant(ST) ? FRAY_BOUNCE_WAVES : FR
 // segment's radiance if it is unobstructed, black otherwise.
 struct ShadowArgs { DScene S; ShadowQueue SQ; QMetaRO meta; TermBuf TB; DStats* st; };
 template <int ST>
-static __global__ __launch_bounds__(256, FRAY_SHADOW_WAVES) void k_pt_shadow(ShadowArgs A)
+static __global__ __launch_bounds__(256, waves_for(ST, FRAY_SHADOW_WAVES)) void k_pt_shadow(ShadowArgs A)
 {
     Cnt c = zero_cnt();
     const QMetaRO meta = A.meta;

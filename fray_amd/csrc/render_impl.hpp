@@ -87,7 +87,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
         if (nItems > 0) {
             hipEvent_t a = pool_event(sc->evPool, 0), b = pool_event(sc->evPool, 1);
             HIP_TRY(hipEventRecord(a, stream));
-            hipLaunchKernelGGL(k_primary<ST>, dim3(persistent_grid(nItems, FRAY_PRIMARY_WAVES)), dim3(256), 0, stream, PrimaryArgs{S, C, F, nItems, d_id, d_dist, sc->d_stats, cursors});
+            hipLaunchKernelGGL(k_primary<ST>, dim3(persistent_grid(nItems, waves_for(ST, FRAY_PRIMARY_WAVES))), dim3(256), 0, stream, PrimaryArgs{S, C, F, nItems, d_id, d_dist, sc->d_stats, cursors});
             HIP_TRY(hipEventRecord(b, stream));
             nTraceEvents = 2;
         }
@@ -100,7 +100,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             if (nItems > 0 && sc->whittedNeedsRecursion) {
                 // workspace: per-thread mt19937 state columns for samples that draw more than 227 words,
                 // then x[397] of every (pixel, sample) seed
-                const int grid = persistent_grid(nItems, FRAY_WHITTED_WAVES);
+                const int grid = persistent_grid(nItems, waves_for(ST, FRAY_WHITTED_WAVES));
                 const size_t colBytes = ((size_t)grid * 256 * 624 * sizeof(uint32_t) + 255) / 256 * 256;
                 int rc = ensure_work(sc, colBytes + (size_t)nItems * spp * sizeof(uint32_t));
                 if (rc) return rc;
@@ -119,7 +119,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 const bool stereo = sc->camera.stereoSeparation > 0;
                 const size_t eyes = stereo ? 2 : 1;
                 auto r256 = [](size_t b) { return (b + 255) / 256 * 256; };
-                const int grid = persistent_grid((size_t)nItems * spp, 4);
+                const int grid = persistent_grid((size_t)nItems * spp, waves_for(ST, FRAY_WH_SHADE_WAVES));
                 const size_t colBytes = r256((size_t)grid * 256 * 624 * sizeof(uint32_t));
                 // per (pixel, sample): base 12 + a 24 + hit 1 + radiance 12 per eye, 37 per light sample and eye, 4 for the seed
                 const size_t perSlot = eyes * (49 + (size_t)T * 37) + 4;

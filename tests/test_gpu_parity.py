@@ -462,14 +462,42 @@ def test_nested_csg_vs_oracle(fray, abi, oracle, gpu, gi):
     s.close()
 
 
+def _csg_chain(tmp_path, levels):
+    """A chain of `levels` CsgOp nodes, each level the union / difference / intersection of the level below and a sphere or cube of its own."""
+    ops = ["CsgPlus", "CsgMinus", "CsgAnd"]
+    txt = ("GlobalSettings {\n\tframeWidth 64\n\tframeHeight 48\n\tambientLight (0.3, 0.3, 0.3)\n}\nPointLight {\n\tpos (30, 40, -60)\n\tpower 12000\n}\n"
+           "Camera camera {\n\tposition (0, 1, -9)\n\tfov 60\n\taspectRatio 1.3333\n}\nCube a {\n\thalfSide 2\n}\n")
+    for k in range(1, levels + 1):
+        txt += "Sphere s%d {\n\tO (%g, %g, %g)\n\tR %g\n}\n" % (k, 0.37 * (k % 5) - 0.8, 0.29 * (k % 3) - 0.3, -1.6 + 0.11 * k, 0.9 + 0.07 * (k % 4))
+        txt += "%s l%d {\n\tleft %s\n\tright s%d\n}\n" % (ops[k % 3] if k % 4 else "CsgPlus", k, "a" if k == 1 else "l%d" % (k - 1), k)
+    txt += "Lambert lam {\n\tcolor (0.8, 0.7, 0.6)\n}\nNode n {\n\tgeometry l%d\n\tshader lam\n}\n" % levels
+    f = tmp_path / ("chain%d.fray" % levels)
+    f.write_text(txt)
+    return str(f)
+
+
+@pytest.mark.parametrize("levels", [9, 16])
+def test_csg_chains_up_to_sixteen_levels_vs_oracle(fray, abi, oracle, gpu, tmp_path, levels):
+    """CsgOp::intersect recurses without bound in the reference (geometry.cpp:139-194); the device unrolls sixteen levels (round 2: eight).  Hit
+    records, counters and the Whitted picture of a 9- and a 16-level chain equal the oracle's."""
+    s = fray.Scene.parseScene(_csg_chain(tmp_path, levels))
+    s.beginRender()
+    ids, dist, st = s.primary_hits(stats=True)
+    oi, od, ost = oracle.render(s.desc, abi.MODE_PRIMARY_ID)
+    assert (oi == 0).sum() > 100                                 # the chain's solid is in the picture
+    assert np.array_equal(ids, oi) and np.array_equal(dist, od)
+    for k in COUNTERS:
+        assert st[k] == ost[k], k
+    img, _ = s.render(seed=42)
+    ref, _ = oracle.render(s.desc, abi.MODE_RENDER, seed=42)
+    assert np.array_equal(img, ref)
+    s.close()
+
+
 def test_unsupported_features_fail_loudly(fray, abi, gpu, tmp_path):
-    f = tmp_path / "nested.fray"
-    levels = "".join("CsgPlus l%d {\n\tleft l%d\n\tright b\n}\n" % (k, k - 1) for k in range(2, 10))
-    f.write_text("Camera camera {\n\tposition (0,0,-5)\n}\nCube a {\n}\nSphere b {\n}\nCsgPlus l1 {\n\tleft a\n\tright b\n}\n" + levels +
-                 "Lambert l {\n}\nNode n {\n\tgeometry l9\n\tshader l\n}\n")
-    s = fray.Scene.parseScene(str(f))
+    s = fray.Scene.parseScene(_csg_chain(tmp_path, 17))
     with pytest.raises(fray.FrayError) as e:
-        s.beginRender()                                         # nine CsgOp levels: one more than the device unrolls
+        s.beginRender()                                         # seventeen CsgOp levels: one more than the device unrolls
     assert e.value.code == abi.E_UNSUPPORTED
     s3 = open_scene(fray, "boxed.fray", 32, 32)
     with pytest.raises(fray.FrayError):

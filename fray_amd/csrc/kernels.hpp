@@ -894,30 +894,35 @@ FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitRec& h, const Te
 // LONG: the generators are MtPath (paths that may draw more than 227 words, i.e. maxTraceDepth >= 20); `LR` says where a path's two
 // 624-word columns live and how to recompute its seed (slot -> pixel, sample).
 struct LongRng { uint32_t* cols; uint32_t nPaths; DFrame F; int nItems, s0; };
-struct BounceArgs { DScene S; PathQueue Qin, Qout; ShadowQueue SQ; QMetaRO metaIn; QMeta* metaOut; QMeta* metaShadow; TermBuf TB; StereoBuf SB; LongRng LR; DStats* st; };
-template <int ST, bool LONG>
+// FIRST: the batch's first bounce makes its own camera rays (what k_pt_init does for the other cases: stereo, long generators) instead of
+// reading them from a queue -- no 92-byte path record written and read back per camera sample, one launch less per batch.
+struct FirstArgs { DCamera C; DFrame F; int nItems, s0; uint32_t n; const uint32_t* x397; unsigned short* termCount; };
+struct BounceArgs { DScene S; PathQueue Qin, Qout; ShadowQueue SQ; QMetaRO metaIn; QMeta* metaOut; QMeta* metaShadow; TermBuf TB; StereoBuf SB; LongRng LR; DStats* st; FirstArgs FA; };
+template <int ST, bool LONG, bool FIRST = false>
 static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOUNCE_WAVES : FRAY_BOUNCE_WAVES_NOKD)) void k_pt_bounce(BounceArgs A)
 {
+    static_assert(!(LONG && FIRST), "long generators start from k_pt_init");
     typedef typename std::conditional<LONG, MtPath, Mt>::type G;
     Cnt c = zero_cnt();
     const QMetaRO metaIn = A.metaIn;
     QMeta* const metaOut = A.metaOut;
     QMeta* const metaShadow = A.metaShadow;
     DStats* const st = A.st;
-    const FRAY_RO uint32_t* off = metaIn.p->off;
-    const uint32_t nSeg = metaIn.p->nSeg, chunkIn = metaIn.p->chunk;
-    const WaveShare ws = wave_share(metaIn.p->n);
+    const FRAY_RO uint32_t* off = FIRST ? nullptr : metaIn.p->off;
+    const uint32_t nSeg = FIRST ? 1u : metaIn.p->nSeg, chunkIn = FIRST ? A.FA.n : metaIn.p->chunk;
+    const WaveShare ws = wave_share(FIRST ? A.FA.n : metaIn.p->n);
     const uint32_t lane = threadIdx.x & 63u;
     SegEnds outEnds{ws.begin, ws.chunk, 0, 0};                                            // wave-uniform
     __shared__ uint32_t shadowCount[4][2];
     if (lane < 2) shadowCount[threadIdx.x >> 6][lane] = 0;
     const SegEndsShared shadowEnds{ws.begin, ws.chunk, shadowCount[threadIdx.x >> 6]};
-    uint32_t seg = ws.begin < ws.end ? seg_first(off, nSeg, ws.begin) : 0;
+    uint32_t seg = (!FIRST && ws.begin < ws.end) ? seg_first(off, nSeg, ws.begin) : 0;
 #ifdef FRAY_STAMPS
     stamp_begin();
 #endif
     for (uint32_t base = ws.begin; base < ws.end; base += 64u) {
         const FRAY_RO BounceArgs* AP = kernel_args<BounceArgs>();
+        const FirstArgs& FA = KARG(BounceArgs, AP, FA);
         const DScene& S = KARG(BounceArgs, AP, S);
         const PathQueue& Qin = KARG(BounceArgs, AP, Qin);
         const PathQueue& Qout = KARG(BounceArgs, AP, Qout);
@@ -929,15 +934,42 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
         bool cont = false, shadow = false, shadowBack = false;
         PathStateT<G> ps;
         bool live = di < ws.end;
-        const uint32_t i = seg_map(off, nSeg, chunkIn, base, di, live, seg);
-        if (live) live = Qin.depthFlags[i] != FRAY_DEAD;
+        uint32_t i = di, seed0 = 0;
+        if constexpr (FIRST) {
+            // the camera sample of slot di (k_pt_init's arithmetic): generators seeded by the contract seed, two jitter words, the lens sample
+            if (live) {
+                FA.termCount[di] = 0;
+                int px, py;
+                live = item_pixel(FA.F, (int)(di % (uint32_t)FA.nItems), px, py);      // slots of a ragged edge bucket outside the frame: no path
+                if (live) {
+                    seed0 = sample_seed(FA.F.seed, (uint32_t)py * (uint32_t)FA.F.W + (uint32_t)px, (uint32_t)(FA.s0 + (int)(di / (uint32_t)FA.nItems)));
+                    Mt rnd = mt_seed_with(seed0, FA.x397[di]), tab = rnd;
+                    const float ox = rng_float(rnd), oy = rng_float(rnd);                  // gi: always jittered (main.cpp:351-353)
+                    const double fx = (double)((float)px + ox), fy = (double)((float)py + oy);
+                    if (FA.C.dof) dof_ray(FA.C, fx, fy, tab, ps.o, ps.d, 0); else screen_ray(FA.C, fx, fy, ps.o, ps.d, 0);
+                }
+            }
+        } else {
+            i = seg_map(off, nSeg, chunkIn, base, di, live, seg);
+            if (live) live = Qin.depthFlags[i] != FRAY_DEAD;
+            if (live) path_load_ray(Qin, i, ps);
+        }
         if (live) {
-            path_load_ray(Qin, i, ps);
             STAMP(0);
             // entry test of pathtrace() (main.cpp:173-176) was applied before this path was queued
             HitRec h;
             closest_hit<ST>(S, ps.o, ps.d, h, c);
-            path_load_rest(Qin, i, ps);
+            if constexpr (FIRST) {
+                // the rest of the path's state, made after the search so that it is not live across it: the generators stand where the camera ray left them
+                ps.pm = c3(1, 1, 1); ps.slot = di; ps.depth = 0; ps.flags = 0;
+                ps.rnd = mt_seed_with(seed0, FA.x397[di]);
+                ps.tab = ps.rnd;
+                mt_skip(ps.rnd, 2);
+                if (FA.C.dof) mt_skip(ps.tab, 4);
+                bump<ST>(c.samples);
+            } else {
+                path_load_rest(Qin, i, ps);
+            }
 #ifdef FRAY_QCHECK
             // diagnostic build: a queue entry that no producer wrote (or that was consumed before) is counted and dropped
             if (ps.slot >= TB.nPaths) { atomicAdd(&st->rngOverflow, 1ull << 32); ps.slot = 0; ps.pm = c3(0, 0, 0); ps.depth = 0x7fff; }

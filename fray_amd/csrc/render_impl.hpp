@@ -177,6 +177,10 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             // stream with its own queues, so one batch's launch gaps, scans and kernel tails are filled by the others'
             // blocks.  Only the resolves are ordered (evResolved): the per-pixel sum runs in sample order.
             int maxLanes = std::max(1, std::min(sc->ptLanes, FRAY_PT_LANES));
+            // The Cube / CSG kernel variants keep their hit lists in scratch memory (17 KB per lane at sixteen CsgOp levels): every stream that runs
+            // one needs its own scratch arena, and three streams asking for theirs at once aborted inside the runtime (tests/test_fuzz_parity.py,
+            // seed 5).  Those scenes run their batches one after the other.
+            if (ST & 2) maxLanes = 1;
             // a small frame (an eighth of 1080p x 64 spp, i.e. one rank's share of an 8-rank run) is cut into fewer, larger batches:
             // measured 15.5 ms on three lanes against 15.9 on four; from a quarter of that frame upwards four lanes win
             if (maxLanes > 3 && (size_t)nItems * (size_t)spp < ((size_t)24 << 20)) maxLanes = 3;
@@ -241,13 +245,18 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 hipStream_t ls = L.stream;
                 hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * cn + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, ls, F, nItems, s0, cn, L.x397);
                 for (int eye = 0; eye < (stereo ? 2 : 1); eye++) {
-                    // queue 0 is dense: one segment holding every slot of the batch
-                    hipLaunchKernelGGL(k_meta_dense, dim3(1), dim3(64), 0, ls, L.meta, (uint32_t)((size_t)nItems * cn));
+                    // A mono frame with register generators makes its camera rays inside the first bounce (k_pt_bounce<.., FIRST>); a stereo frame (the
+                    // right eye continues the left eye's streams) and long generators start from a dense queue written by k_pt_init
+                    const bool fused = !stereo && !longRng;
                     float* rad = eye == 0 ? L.sampleRad : L.sampleRadR;
                     // left pass of a stereo frame saves generator cursors at path end; mono and the right pass do not
                     const StereoBuf& save = (stereo && eye == 0) ? L.SB : SBnone;
-                    hipLaunchKernelGGL(k_pt_init<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, ls, S, C, F, nItems, s0, cn, L.Q[0],
-                                       L.termCount, L.x397, L.SB, eye, sc->d_stats);
+                    if (!fused) {
+                        // queue 0 is dense: one segment holding every slot of the batch
+                        hipLaunchKernelGGL(k_meta_dense, dim3(1), dim3(64), 0, ls, L.meta, (uint32_t)((size_t)nItems * cn));
+                        hipLaunchKernelGGL(k_pt_init<ST>, dim3(grid_for((size_t)nItems * cn)), dim3(256), 0, ls, S, C, F, nItems, s0, cn, L.Q[0],
+                                           L.termCount, L.x397, L.SB, eye, sc->d_stats);
+                    }
                     for (int b = 0; b < nBounce; b++) {
                         const QMetaRO mIn{(const FRAY_RO QMeta*)(L.meta + (b & 1))}, mSh{(const FRAY_RO QMeta*)(L.meta + 2)};
                         const int grid = bounce_grid((size_t)nItems * cn);
@@ -257,8 +266,10 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                         HIP_TRY(hipEventRecord(ea, ls));
                         const LongRng LR{L.mtCols, (uint32_t)nPaths, F, nItems, s0};
                         const TermBuf TB{L.terms, L.termCount, (uint32_t)nPaths, b};
-                        const BounceArgs BA{S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ, mIn, L.meta + ((b + 1) & 1), L.meta + 2, TB, save, LR, sc->d_stats};
+                        const FirstArgs FA{C, F, nItems, s0, (uint32_t)((size_t)nItems * cn), L.x397, L.termCount};
+                        const BounceArgs BA{S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ, mIn, L.meta + ((b + 1) & 1), L.meta + 2, TB, save, LR, sc->d_stats, FA};
                         if (longRng) hipLaunchKernelGGL((k_pt_bounce<ST, true>), dim3(grid), dim3(256), 0, ls, BA);
+                        else if (fused && b == 0) hipLaunchKernelGGL((k_pt_bounce<ST, false, true>), dim3(grid), dim3(256), 0, ls, BA);
                         else hipLaunchKernelGGL((k_pt_bounce<ST, false>), dim3(grid), dim3(256), 0, ls, BA);
                         HIP_TRY(hipEventRecord(eb, ls));
                         nTraceEvents += 2;

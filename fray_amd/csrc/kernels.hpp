@@ -663,7 +663,7 @@ static __global__ __launch_bounds__(1024) void k_scan(QMeta* m0, QMeta* m1)
 // Queue 0 of a batch is dense: a single segment that holds every slot.
 static __global__ void k_meta_dense(QMeta* m, uint32_t n)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { m->n = n; m->chunk = n; m->nSeg = 1; m->pad = 0; m->off[0] = 0; m->off[1] = n; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { m->n = n; m->chunk = n; m->nSeg = 1; m->pad = 0; m->nf[0] = n; m->off[0] = 0; m->off[1] = n; }
 }
 
 // Dense index -> storage index of a segmented queue without a table in LDS: a wave walks a contiguous range of
@@ -679,14 +679,14 @@ FD uint32_t seg_first(const FRAY_RO uint32_t* off, uint32_t nSeg, uint32_t begin
     }
     return lo;
 }
-FD uint32_t run_slot(uint32_t run, uint32_t chunk, uint32_t e) { return (run >> 1) * chunk + ((run & 1u) ? chunk - 1u - e : e); }
-FD uint32_t seg_map(const FRAY_RO uint32_t* off, uint32_t nSeg, uint32_t chunk, uint32_t base, uint32_t di, bool live, uint32_t& seg)
+FD uint32_t seg_slot_of(uint32_t s, uint32_t chunk, uint32_t e, uint32_t nf) { return s * chunk + (e < nf ? e : chunk - 1u - (e - nf)); }
+FD uint32_t seg_map(const FRAY_RO uint32_t* off, const FRAY_RO uint32_t* nf, uint32_t nSeg, uint32_t chunk, uint32_t base, uint32_t di, bool live, uint32_t& seg)
 {
     while (seg + 1 < nSeg && off[seg + 1] <= base) seg++;
     uint32_t i = 0, s = seg, lo = off[s];
-    for (;;) {                        // the runs that overlap this batch: one, now and then two
+    for (;;) {                        // the segments that overlap this batch: one, now and then two
         const uint32_t hi = off[s + 1];
-        if (live && di >= lo && di < hi) i = run_slot(s, chunk, di - lo);
+        if (live && di >= lo && di < hi) i = seg_slot_of(s, chunk, di - lo, nf[s]);
         if (hi >= base + 64u || s + 1 >= nSeg) break;
         s++;
         lo = hi;
@@ -909,6 +909,7 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
     QMeta* const metaShadow = A.metaShadow;
     DStats* const st = A.st;
     const FRAY_RO uint32_t* off = FIRST ? nullptr : metaIn.p->off;
+    const FRAY_RO uint32_t* nfIn = FIRST ? nullptr : metaIn.p->nf;
     const uint32_t nSeg = FIRST ? 1u : metaIn.p->nSeg, chunkIn = FIRST ? A.FA.n : metaIn.p->chunk;
     const WaveShare ws = wave_share(FIRST ? A.FA.n : metaIn.p->n);
     const uint32_t lane = threadIdx.x & 63u;
@@ -950,7 +951,7 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
                 }
             }
         } else {
-            i = seg_map(off, nSeg, chunkIn, base, di, live, seg);
+            i = seg_map(off, nfIn, nSeg, chunkIn, base, di, live, seg);
             if (live) live = Qin.depthFlags[i] != FRAY_DEAD;
             if (live) path_load_ray(Qin, i, ps);
         }
@@ -1000,10 +1001,10 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
     if (lane < 16) atomicAdd(&st->stamp[lane], g_stampAcc[threadIdx.x >> 6][lane]);
 #endif
     if (lane == 0) {
-        metaOut->cnt[2 * ws.w] = outEnds.nF; metaOut->cnt[2 * ws.w + 1] = outEnds.nB;
-        metaShadow->cnt[2 * ws.w] = shadowCount[threadIdx.x >> 6][0]; metaShadow->cnt[2 * ws.w + 1] = shadowCount[threadIdx.x >> 6][1];
+        metaOut->cnt[ws.w] = outEnds.nF + outEnds.nB; metaOut->nf[ws.w] = outEnds.nF;
+        metaShadow->cnt[ws.w] = shadowCount[threadIdx.x >> 6][0] + shadowCount[threadIdx.x >> 6][1]; metaShadow->nf[ws.w] = shadowCount[threadIdx.x >> 6][0];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { metaOut->chunk = ws.chunk; metaOut->nSeg = 2 * ws.W; metaShadow->chunk = ws.chunk; metaShadow->nSeg = 2 * ws.W; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { metaOut->chunk = ws.chunk; metaOut->nSeg = ws.W; metaShadow->chunk = ws.chunk; metaShadow->nSeg = ws.W; }
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
@@ -1018,6 +1019,7 @@ static __global__ __launch_bounds__(256, waves_for(ST, FRAY_SHADOW_WAVES)) void 
     const QMetaRO meta = A.meta;
     DStats* const st = A.st;
     const FRAY_RO uint32_t* off = meta.p->off;
+    const FRAY_RO uint32_t* nfIn = meta.p->nf;
     const uint32_t nSeg = meta.p->nSeg, chunkIn = meta.p->chunk;
     const WaveShare ws = wave_share(meta.p->n);
     const uint32_t lane = threadIdx.x & 63u;
@@ -1033,7 +1035,7 @@ static __global__ __launch_bounds__(256, waves_for(ST, FRAY_SHADOW_WAVES)) void 
         const TermBuf& TB = KARG(ShadowArgs, AP, TB);
         const uint32_t di = base + lane;
         const bool live = di < ws.end;
-        const uint32_t i = seg_map(off, nSeg, chunkIn, base, di, live, seg);
+        const uint32_t i = seg_map(off, nfIn, nSeg, chunkIn, base, di, live, seg);
         if (live) {
             const V3 a = v3(SQ.ax[i], SQ.ay[i], SQ.az[i]), b = v3(SQ.bx[i], SQ.by[i], SQ.bz[i]);
             STAMP(0);

@@ -354,6 +354,8 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     }
     size_t oNodes = A.add(nullptr, 0);                  // filled after the meshes: tree-less nodes hold a device pointer
     A.host.resize(oNodes + nodes.size() * sizeof(DNode));
+    size_t oNodesX = A.add(nullptr, 0);
+    A.host.resize(oNodesX + nodes.size() * sizeof(DNodeX));
     size_t oGates = A.add(nullptr, 0);                  // the path tracer's scheduling hint (DGate), filled with the nodes
     A.host.resize(oGates + FRAY_MAX_GATES * sizeof(DGate));
     std::vector<DPlane> planes(d.n_planes);
@@ -521,18 +523,22 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         meshes[mi].ltris = (const FRAY_RO DTri*)(base + moff[mi].ltris);
     }
     if (!meshes.empty()) memcpy(A.host.data() + oMeshes, meshes.data(), meshes.size() * sizeof(DMesh));
+    std::vector<DNodeX> nodesX(nodes.size());
     for (int i = 0; i < d.n_nodes; i++) {
         DNode& N = nodes[i];
+        DNodeX& X = nodesX[i];
         N.tlTris = 0; N.tlCulling = 0; N.pad = 0; N.tlPtr = nullptr; N.boxMax = 0;
-        for (int k = 0; k < 3; k++) N.bmin[k] = N.bmax[k] = 0;
+        for (int k = 0; k < 3; k++) N.bmin[k] = N.bmax[k] = X.bminE[k] = X.bmaxE[k] = 0;
         if (N.geomKind == FRAYHIP_GEOM_MESH && !meshes[N.geomIndex].hasKd) {
             const DMesh& M = meshes[N.geomIndex];
             N.tlTris = M.nTris; N.tlCulling = M.culling; N.tlPtr = M.tris;
             put3(N.bmin, M.bmin); put3(N.bmax, M.bmax);
             N.boxMax = M.boxMax;
+            for (int k = 0; k < 3; k++) { X.bminE[k] = N.bmin[k] - 1e-6; X.bmaxE[k] = N.bmax[k] + 1e-6; }
         }
     }
     if (!nodes.empty()) memcpy(A.host.data() + oNodes, nodes.data(), nodes.size() * sizeof(DNode));
+    if (!nodesX.empty()) memcpy(A.host.data() + oNodesX, nodesX.data(), nodesX.size() * sizeof(DNodeX));
     // gates: world-space boxes of the meshes whose brute-force triangle loops are worth skipping for a whole wave (dev_scene.hpp DGate):
     // the eight corners of the mesh's box through the node's transform (Transform::transformPoint, matrix.cpp:137-146), a hair wider
     int nGates = 0;
@@ -563,6 +569,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
 
     DScene& S = sc->S;
     S.nodes = (const FRAY_RO DNode*)(base + oNodes);
+    S.nodesX = (const FRAY_RO DNodeX*)(base + oNodesX);
     S.gates = (const FRAY_RO DGate*)(base + oGates);
     S.nGates = nGates; S.padGates = 0;
     S.planes = (const FRAY_RO DPlane*)(base + oPlanes);

@@ -54,6 +54,10 @@ struct DNode {
     const FRAY_RO DTri* tlPtr;
     double boxMax;        // max |coordinate| of bmin / bmax (margins of the certified box test, dev_boxcert.hpp)
 };                        // 264 B
+// What only the box test of the scenes WITHOUT KD meshes reads (DScene::nodesX): the node's box widened by inside()'s tolerance
+struct DNodeX {
+    double bminE[3], bmaxE[3];   // bmin - 1e-6, bmax + 1e-6: what BBox::inside compares with (bbox.h:81-83), computed once on the host
+};
 
 struct DPlane { double limit, height; };
 struct DSphere { double O[3]; double R; };
@@ -157,6 +161,7 @@ struct DGate { double lo[3], hi[3]; };
 
 struct DScene {
     const FRAY_RO DNode* nodes;
+    const FRAY_RO DNodeX* nodesX;
     const FRAY_RO DGate* gates;
     int32_t nGates, padGates;
     const FRAY_RO DPlane* planes;

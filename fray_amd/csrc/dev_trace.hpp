@@ -722,8 +722,10 @@ FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c)
 {
     bump<ST>(c.shadow);
     V3 d = b - a;
-    double maxDist = length(a - b);
-    d = normalized(d);
+    // main.cpp:66-70 takes distance(a, b) = length(a - b) and then normalises b - a, i.e. divides by length(b - a): the two lengths are the same
+    // bits (a - b is exactly -(b - a), and squares do not see the sign), so one square root serves both
+    const double maxDist = length(d);
+    d = d * (1.0 / maxDist);
     const int nn = S.nNodes;
     LocalRay lr;
     lr.cls = -1;

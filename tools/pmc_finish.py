@@ -19,13 +19,16 @@ def main():
     raw = json.load(open(os.path.join(out_dir, "pmc_raw.json")))
     # kernel trace of the serialised run: average duration per kernel
     dur = {}
-    for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    for f in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv"), recursive=True) or glob.glob(os.path.join(out_dir, "kernel_trace.csv")):
         for row in csv.DictReader(open(f, newline="")):
             k = row["Kernel_Name"].split("(")[0].replace("void ", "")
             d = dur.setdefault(k, [0, 0.0])
             d[0] += 1
             d[1] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
     kernels = {}
+    # every timed variant of a kernel counts (e.g. k_pt_bounce<0, false, false> and the batches' first bounce <0, false, true>): counters and
+    # durations are pooled per kernel name, so that the per-launch figures are averages over the launches of a frame, as bench.py's are
+    pooled = {}
     for name, v in raw.items():
         k = name.replace("void ", "")
         base = k.split("<")[0]
@@ -35,11 +38,21 @@ def main():
             flag = k.split("<")[1].split(",")[0].split(">")[0].strip()
             if flag.lstrip("-").isdigit() and (int(flag) & 1):
                 continue                  # bit 0 of the flag word = the variant that maintains the work counters: only the others are the timed ones
-        per = {c: e["total"] / max(1, e["launches"]) for c, e in v.items() if isinstance(e, dict) and "total" in e}
-        rec = {"launches_profiled": max([e["launches"] for c, e in v.items() if isinstance(e, dict) and "launches" in e] or [0]), "per_launch": per}
+        g = pooled.setdefault(base, {"counters": {}, "variants": [], "dur": [0, 0.0]})
+        g["variants"].append(k)
+        for c, e in v.items():
+            if isinstance(e, dict) and "total" in e:
+                t = g["counters"].setdefault(c, [0.0, 0])
+                t[0] += e["total"]; t[1] += e["launches"]
         if k in dur:
-            rec["avg_launch_ms"] = dur[k][1] / dur[k][0]
-            rec["launches_traced"] = dur[k][0]
+            g["dur"][0] += dur[k][0]; g["dur"][1] += dur[k][1]
+    for base, g in pooled.items():
+        per = {c: t[0] / max(1, t[1]) for c, t in g["counters"].items()}
+        rec = {"launches_profiled": max([t[1] for t in g["counters"].values()] or [0]), "per_launch": per, "variants": sorted(g["variants"])}
+        if g["dur"][0]:
+            rec["avg_launch_ms"] = g["dur"][1] / g["dur"][0]
+            rec["launches_traced"] = g["dur"][0]
+        k = base
         d = {}
         simd_cycles = per["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0 if per.get("GRBM_GUI_ACTIVE") else None     # GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs
         if "SQ_ACTIVE_INST_VALU" in per and simd_cycles:
@@ -80,10 +93,7 @@ def main():
             rec["hbm_note"] = ("rocprofv3 --pmc, separate passes: FETCH_SIZE %.4g KB + WRITE_SIZE %.4g KB per launch, raw.  On gfx950 FETCH_SIZE reads half the bytes of a "
                                "16-B-per-lane stream; this kernel reads 8 and 4 B per lane (uncalibrated width), so the truth lies between raw and *_fetch_doubled"
                                % (per["FETCH_SIZE"], per["WRITE_SIZE"]))
-        rec["variant"] = k
-        prev = kernels.get(base)
-        if prev is None or rec["launches_profiled"] > prev["launches_profiled"]:      # e.g. k_pt_bounce<0, false> and <0, true>: the one that ran
-            kernels[base] = rec
+        kernels[base] = rec
     res = {"source_hash": source_hash(), "workload": workload, "mode": "FRAYHIP_PT_LANES=1 (serialised launches)", "kernels": kernels}
     json.dump(res, open(os.path.join(out_dir, "pmc.json"), "w"), indent=1)
     for k, r in sorted(kernels.items()):

@@ -35,4 +35,5 @@ python3 tools/pmc_finish.py $OUT $WL > $OUT/pmc.txt 2>&1
 cat $OUT/pmc.txt
 # keep what profiles/ wants in a few small files (the per-pass directories stay on the box's scratch copy)
 cp "$(ls -t $OUT/trace/*/*_kernel_stats.csv | head -1)" $OUT/kernel_stats.csv 2>/dev/null || true
+cp "$(ls -t $OUT/trace/*/*_kernel_trace.csv | head -1)" $OUT/kernel_trace.csv 2>/dev/null || true
 rm -rf $OUT/p[0-9]* $OUT/trace

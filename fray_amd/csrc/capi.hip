@@ -378,7 +378,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     size_t oCsgs = A.add(csgs.data(), csgs.size() * sizeof(DCsg));
     // meshes
     std::vector<DMesh> meshes(d.n_meshes);
-    struct MeshOff { size_t tris, attrs, kd, refs, ltris; };
+    struct MeshOff { size_t tris, attrs, kd, refs, ltris, ltris32; };
     std::vector<MeshOff> moff(d.n_meshes);
     for (int mi = 0; mi < d.n_meshes; mi++) {
         const frayhip_mesh& m = d.meshes[mi];
@@ -453,6 +453,11 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         std::vector<DTri> ltris((size_t)m.n_trirefs);
         for (int r = 0; r < m.n_trirefs; r++) ltris[r] = tris[m.trirefs[r]];
         moff[mi].ltris = A.add(ltris.data(), ltris.size() * sizeof(DTri));
+        // the same leaf order again as FP32 records of the certified filter (dev_tricert.hpp), relative to the centre of the mesh's box
+        for (int k = 0; k < 3; k++) M.ref[k] = (m.bbox_min[k] + m.bbox_max[k]) * 0.5;
+        std::vector<DTri32> l32(ltris.size());
+        for (size_t r = 0; r < ltris.size(); r++) tricert_make(l32[r], ltris[r].A, ltris[r].AB, ltris[r].AC, ltris[r].N, M.ref);
+        moff[mi].ltris32 = A.add(l32.data(), l32.size() * sizeof(DTri32));
     }
     size_t oTexels = A.add(d.texels, (size_t)d.n_texels * sizeof(float));
     std::vector<DTexture> tex(d.n_textures);
@@ -521,6 +526,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         meshes[mi].kd = (const FRAY_RO DKd*)(base + moff[mi].kd);
         meshes[mi].refs = (const FRAY_RO int32_t*)(base + moff[mi].refs);
         meshes[mi].ltris = (const FRAY_RO DTri*)(base + moff[mi].ltris);
+        meshes[mi].ltris32 = (const FRAY_RO DTri32*)(base + moff[mi].ltris32);
     }
     if (!meshes.empty()) memcpy(A.host.data() + oMeshes, meshes.data(), meshes.size() * sizeof(DMesh));
     std::vector<DNodeX> nodesX(nodes.size());

@@ -15,6 +15,7 @@
 #pragma once
 #include <stdint.h>
 #include "frayhip.h"      // FRAYHIP_BUCKET_SKEW: the bucket numbering is part of the C ABI
+#include "dev_tricert.hpp"  // DTri32
 
 // Scene tables are read-only for the whole frame.  On the device their pointers are typed into the
 // constant address space (4): loads through them are known not to alias the kernels' stores, so a
@@ -105,6 +106,9 @@ struct DMesh {
     const FRAY_RO DTri* ltris;
     int32_t nTris, hasKd, smooth, culling, hasUV, pad;
     double boxMax;     // max |coordinate| of the bounding box (margins of the certified box test, dev_boxcert.hpp)
+    // beside ltris, same order: the FP32 records of the certified "surely misses" filter (dev_tricert.hpp), relative to `ref`
+    const FRAY_RO DTri32* ltris32;
+    double ref[3];     // centre of the bounding box
 };
 
 struct DTexture {

@@ -354,9 +354,35 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
             const int beg = kd[leaf].triBegin, cnt = kd[leaf].triCount;
             bool found = false;
             const FRAY_RO DTri* lt = M.ltris + beg;
-            for (int t = 0; t < cnt; t++) {
-                bump<ST>(c.leafRefs);
-                if (tri_test<ST>(lt + t, culling, s, d, gamma, l2, l3, c)) { found = true; tri = lt[t].index; }
+            const FRAY_RO DTri32* lf = M.ltris32 + beg;
+            // the ray as the certified triangle filter reads it (dev_tricert.hpp): FP32, relative to the mesh's reference point.  Made again in
+            // every leaf (nine instructions) rather than kept in seven registers through the walk
+            // (the empty asm keeps the optimiser from hoisting the conversions out of the walk's loop, where they would hold those registers)
+            double hx = s.x, hy = s.y, hz = s.z, hdx = d.x, hdy = d.y, hdz = d.z;
+            asm volatile("" : "+v"(hx), "+v"(hy), "+v"(hz), "+v"(hdx), "+v"(hdy), "+v"(hdz));
+            const float s32x = (float)(hx - M.ref[0]), s32y = (float)(hy - M.ref[1]), s32z = (float)(hz - M.ref[2]);
+            const float d32x = (float)hdx, d32y = (float)hdy, d32z = (float)hdz;
+            const bool rayOk32 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(s32x), __builtin_fabsf(s32y)), __builtin_fabsf(s32z)) <= 1e9f;
+            // two passes over (at most 32 at a time of) the leaf's triangles: the certified FP32 filter marks the ones the reference's test may
+            // accept (dev_tricert.hpp: the others it surely rejects, and a rejected triangle leaves no trace), then the reference's arithmetic
+            // runs on the marked ones in their order.  A wave spends its FP64 tests on max-over-lanes CANDIDATES instead of triangles.
+            for (int base = 0; base < cnt; base += 32) {
+                const int m = cnt - base < 32 ? cnt - base : 32;
+                unsigned cand = 0;
+                for (int t = 0; t < m; t++) {
+                    bump<ST>(c.leafRefs);
+                    const FRAY_RO DTri32* r = lf + base + t;
+                    const bool miss = rayOk32 && tri_sure_miss(r->A[0], r->A[1], r->A[2], r->AB[0], r->AB[1], r->AB[2], r->AC[0], r->AC[1], r->AC[2], r->Lq, r->Cq,
+                                                               s32x, s32y, s32z, d32x, d32y, d32z);
+                    if (miss) bump<ST>(c.tri);           // the reference ran (and failed) its test on this one too
+                    else cand |= 1u << t;
+                }
+                STAMP(15);
+                while (cand) {
+                    const int t = base + __builtin_ctz(cand);
+                    cand &= cand - 1;
+                    if (tri_test<ST>(lt + t, culling, s, d, gamma, l2, l3, c)) { found = true; tri = lt[t].index; }
+                }
             }
             STAMP(11);
             if (found && box_inside(kd_box(kd + leaf), s + d * gamma)) return true;

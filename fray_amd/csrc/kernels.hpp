@@ -46,12 +46,17 @@ constexpr int waves_for(int st, int n) { return (st & 2) ? (FRAY_CSG_WAVES < n ?
 #ifndef FRAY_SHADOW_WAVES
 #define FRAY_SHADOW_WAVES 5     // the any-hit kernels at 96 VGPRs (13 / 8 spilled): boxed Whitted 12.0 -> 11.3 ms, headline -1 % against 4 waves
 #endif
+#ifndef FRAY_ANYHIT_WAVES_KD
+#define FRAY_ANYHIT_WAVES_KD 4  // k_primary / k_wh_visible / k_pt_shadow beside KD meshes: the walk with its two-pass leaves wants 117-125 VGPRs; at 5 waves (96, 30-40 spilled, some
+#endif                          // inside the child-test loop) boxed Whitted 12.1 ms, at 4 waves 8.0; dragon primary 0.80 -> 0.78, forest DOF 16 13.0 -> 12.2
 #ifndef FRAY_BOUNCE_WAVES
 #define FRAY_BOUNCE_WAVES 4   // waves per SIMD the bounce kernel is register-allocated for: 128 VGPRs, 2 spilled (3 waves: 129 VGPRs; headline 123.5 vs 116.2 ms)
 #endif
 #ifndef FRAY_BOUNCE_WAVES_NOKD
 #define FRAY_BOUNCE_WAVES_NOKD 5   // the variants without the KD walk need 100-106 VGPRs: 5 waves/SIMD at 94-96, 0-7 spilled (headline 111.8 -> 108.7 ms against 4 waves)
 #endif
+constexpr int primary_waves(int st) { return waves_for(st, kd_variant(st) ? FRAY_ANYHIT_WAVES_KD : FRAY_PRIMARY_WAVES); }
+constexpr int anyhit_waves(int st) { return waves_for(st, kd_variant(st) ? FRAY_ANYHIT_WAVES_KD : FRAY_SHADOW_WAVES); }
 
 // ---- kernel arguments, read where they are used ------------------------------------------------------------
 // A kernel's by-value arguments are all loaded at its entry and kept alive; in the big kernels most of them (scene tables, queue
@@ -193,7 +198,7 @@ static __global__ __launch_bounds__(256) void k_seed(DFrame F, int nItems, int s
 // ---- MODE_PRIMARY_ID ------------------------------------------------------------------------------
 struct PrimaryArgs { DScene S; DCamera C; DFrame F; int nItems; int32_t* hitId; double* hitDist; DStats* st; DCursors* cur; };
 template <int ST>
-static __global__ __launch_bounds__(256, waves_for(ST, FRAY_PRIMARY_WAVES)) void k_primary(PrimaryArgs A)
+static __global__ __launch_bounds__(256, primary_waves(ST)) void k_primary(PrimaryArgs A)
 {
     Cnt c = zero_cnt();
     const int nItems = A.nItems;
@@ -531,7 +536,7 @@ static __global__ __launch_bounds__(256, waves_for(ST, FRAY_WH_SHADE_WAVES)) voi
 
 struct WhVisibleArgs { DScene S; WhittedQueue Q; size_t N; int T; DStats* st; };
 template <int ST>
-static __global__ __launch_bounds__(256, waves_for(ST, FRAY_SHADOW_WAVES)) void k_wh_visible(WhVisibleArgs A)
+static __global__ __launch_bounds__(256, anyhit_waves(ST)) void k_wh_visible(WhVisibleArgs A)
 {
     Cnt c = zero_cnt();
     const size_t N = A.N;
@@ -1013,7 +1018,7 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
 // segment's radiance if it is unobstructed, black otherwise.
 struct ShadowArgs { DScene S; ShadowQueue SQ; QMetaRO meta; TermBuf TB; DStats* st; };
 template <int ST>
-static __global__ __launch_bounds__(256, waves_for(ST, FRAY_SHADOW_WAVES)) void k_pt_shadow(ShadowArgs A)
+static __global__ __launch_bounds__(256, anyhit_waves(ST)) void k_pt_shadow(ShadowArgs A)
 {
     Cnt c = zero_cnt();
     const QMetaRO meta = A.meta;

@@ -87,7 +87,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
         if (nItems > 0) {
             hipEvent_t a = pool_event(sc->evPool, 0), b = pool_event(sc->evPool, 1);
             HIP_TRY(hipEventRecord(a, stream));
-            hipLaunchKernelGGL(k_primary<ST>, dim3(persistent_grid(nItems, waves_for(ST, FRAY_PRIMARY_WAVES))), dim3(256), 0, stream, PrimaryArgs{S, C, F, nItems, d_id, d_dist, sc->d_stats, cursors});
+            hipLaunchKernelGGL(k_primary<ST>, dim3(persistent_grid(nItems, primary_waves(ST))), dim3(256), 0, stream, PrimaryArgs{S, C, F, nItems, d_id, d_dist, sc->d_stats, cursors});
             HIP_TRY(hipEventRecord(b, stream));
             nTraceEvents = 2;
         }
@@ -306,8 +306,8 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
 #ifdef FRAY_STAMPS
     {
         static const char* names[16] = {"queue lookup + ray load / camera ray", "local ray (transform)", "root box test", "tree-less triangle loop", "KD walk: child tests", "other geometry (plane / sphere / KD leaf accept)",
-                                        "node result + world distance", "lights", "load rest of path", "KD walk: climbs", "shading (finalize .. spawn / light loops)", "KD leaves: triangle tests",
-                                        "k_whitted: cheap steps (returns, loop heads, pushes; pixel / sample set-up)", "queue stores / loop overhead", "k_whitted: rest of the trace step (attributes, bump)", "-"};
+                                        "node result + world distance", "lights", "load rest of path", "KD walk: climbs", "shading (finalize .. spawn / light loops)", "KD leaves: FP64 tests of the candidates",
+                                        "k_whitted: cheap steps (returns, loop heads, pushes; pixel / sample set-up)", "queue stores / loop overhead", "k_whitted: rest of the trace step (attributes, bump)", "KD leaves: FP32 filter"};
         for (int q = 0; q < 2; q++) {
             double tot = 0;
             for (int k = 0; k < 16; k++) tot += (double)dsv[q].stamp[k];

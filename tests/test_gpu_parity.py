@@ -804,3 +804,48 @@ def test_textured_scene_without_kd_meshes_vs_oracle(fray, abi, oracle, gpu, tmp_
     for k in ("samples", "closest_rays", "shadow_rays"):
         assert st[k] == ost[k], k
     s.close()
+
+
+@pytest.mark.parametrize("what", ["normal_not_the_cross_product", "coordinates_beyond_the_filter"])
+def test_kd_leaf_filter_guards_vs_oracle(fray, abi, oracle, gpu, what):
+    """The certified FP32 filter of the KD leaves (fray_amd/csrc/dev_tricert.hpp) may only skip triangles the reference's arithmetic rejects.  Two
+    scene descriptions where geometry and arithmetic part ways: (a) a mesh whose stored ABcrossAC is NOT the cross product of its AB and AC
+    (Triangle::intersectFast, triangle.cpp:66-97, believes the stored vectors: lambda2 / lambda3 come out halved, rays 'hit' outside the triangles);
+    (b) edge vectors scaled so that |AB|, |AC| leave the range the filter's FP32 products are proved for.  Both must fall back to the reference's
+    arithmetic for every triangle: hit records bit-equal to the oracle's, counters equal."""
+    s = open_scene(fray, "boxed.fray", 160, 120, wantAA=0)
+    d = s.desc
+    changed = 0
+    for mi in range(d.n_meshes):
+        m = d.meshes[mi]
+        if not m.has_kd:
+            continue
+        for t in range(m.n_triangles):
+            T = m.triangles[t]
+            if what == "normal_not_the_cross_product":
+                if t % 3 == 0:
+                    for k in range(3):
+                        T.ABcrossAC[k] *= 2.0
+                    changed += 1
+            elif t % 5 == 0:
+                for k in range(3):                       # the same plane and (lambda2, lambda3) scaled by 2^-41: the oracle still hits some of them
+                    T.AB[k] *= 2.0 ** 41
+                    T.AC[k] *= 2.0 ** 41
+                    T.ABcrossAC[k] *= 2.0 ** 82
+                changed += 1
+    assert changed > 1000
+    s.beginRender()
+    ids, dist, st = s.primary_hits(stats=True)
+    rid, rdist, ost = oracle.render(s.desc, abi.MODE_PRIMARY_ID)
+    assert np.array_equal(ids, rid) and np.array_equal(dist, rdist)
+    for k in COUNTERS:
+        assert st[k] == ost[k], k
+    img, _ = s.render(seed=42)
+    ref, _ = oracle.render(s.desc, abi.MODE_RENDER, seed=42)
+    assert np.array_equal(img, ref)
+    plain = open_scene(fray, "boxed.fray", 160, 120, wantAA=0)
+    plain.beginRender()
+    pid, _, _ = plain.primary_hits(stats=True)
+    assert (pid != ids).mean() > 0.002                   # the change is visible: the case does exercise the guard
+    plain.close()
+    s.close()

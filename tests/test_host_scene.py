@@ -389,3 +389,22 @@ def test_certified_box_test_never_contradicts_the_reference_arithmetic(tmp_path)
     assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout + r.stderr
     n_true = int(r.stdout.split("surely true")[1].split()[0])
     assert n_true > 100000, r.stdout            # the harness must actually classify
+
+
+def test_certified_triangle_filter_never_rejects_what_the_reference_accepts(tmp_path):
+    """dev_tricert.hpp (the FP32 "surely misses" filter the KD leaves run before Triangle::intersectFast's arithmetic) compiled for the host: over
+    adversarial rays -- aimed at edges and vertices with offsets down to 1e-17 of the triangle, grazing its plane, starting on it, from up to 1e5
+    triangle sizes away, at slivers and at triangles of 1e-9 .. 1e6 units far from the mesh's reference point -- a triangle the filter calls
+    surely rejected is never accepted by the reference's own arithmetic (triangle.cpp:66-97, restated in the harness, minDist = INF, no culling).
+    With the error bound scaled down to 1e-7 the same harness reports contradictions, so it does see them."""
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    exe = str(tmp_path / "tricert_check")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I" + os.path.join(root, "fray_amd", "csrc"),
+                    os.path.join(root, "tests", "native", "tricert_check.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe, "1500000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout + r.stderr
+    assert int(r.stdout.split("surely rejected")[1].split()[0]) > 300000, r.stdout       # the harness must actually filter
+    assert int(r.stdout.split("reference accepts")[1].split()[0]) > 500000, r.stdout     # ... and aim at triangles
+    r = subprocess.run([exe, "1500000", "1e-7"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "mismatches 0" not in r.stdout, r.stdout

@@ -4,6 +4,11 @@ TAG=${1:-r03}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 python tools/source_hash.py > $OUT/source_hash.txt
+# 0. kernel trace + counters, serialised launches, for the workloads DESIGN.md quotes counters of -- FIRST, and put where bench.py looks
+#    for them (profiles/pmc_latest_<workload>.json in this box's copy of the tree), so that the bench lines below carry `traffic` and `counters`
+for w in cornell_pt64 forest_dof16 dragon_primary boxed_whitted dragon_whitted smallpt_pt64; do
+  bash tools/profile_workload.sh ${TAG}_$w $w > $OUT/profile_$w.log 2>&1; cp gpurun_out/prof_${TAG}_$w/pmc.json profiles/pmc_latest_$w.json; echo "profile $w done" >> $OUT/progress.log
+done
 # 1. headline, default mode, with the CPU baseline leg
 timeout -k 10 600 python bench.py --steps 20 --warmup 2 > $OUT/bench_headline.json 2> $OUT/bench_headline.err; echo "headline done" >> $OUT/progress.log
 # 2. the other workloads (one GPU)
@@ -14,10 +19,6 @@ timeout -k 10 300 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-se
 # 3. headline under smaller queue budgets
 for mib in 4096 8192; do
   FRAYHIP_PT_BUDGET_MIB=$mib timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_headline_budget_${mib}mib.json 2> /dev/null; echo "budget $mib done" >> $OUT/progress.log
-done
-# 4. kernel trace + counters, serialised launches, for the workloads DESIGN.md quotes counters of
-for w in cornell_pt64 forest_dof16 dragon_primary boxed_whitted dragon_whitted smallpt_pt64; do
-  bash tools/profile_workload.sh ${TAG}_$w $w > $OUT/profile_$w.log 2>&1; echo "profile $w done" >> $OUT/progress.log
 done
 # 5. every rank's share of an N-rank run, on this one GPU (a prediction of the compute side, not a scaling measurement)
 timeout -k 10 300 python tools/shard_balance.py $OUT/shard_balance.json > $OUT/shard_balance.log 2>&1; echo "shard balance done" >> $OUT/progress.log

@@ -425,6 +425,10 @@ def main():
                 if pmc.get("source_hash") == src and pmc.get("workload") == args.workload:
                     for key in ("roofline", "roofline_shadow_kernel", "roofline_shade_kernel"):
                         k = pmc["kernels"].get(out[key]["kernel"]) if key in out else None
+                        # per-launch figures only describe launches of the profiled size (another queue budget cuts the frame into other launches)
+                        if k and k.get("avg_launch_ms") and not 0.75 <= out[key]["avg_launch_ms"] / k["avg_launch_ms"] <= 1.33:
+                            out[key]["counters_note"] = "%s was taken with launches of %.3f ms: not this configuration's" % (os.path.relpath(pmc_path, ROOT), k["avg_launch_ms"])
+                            k = None
                         if k:
                             out[key]["traffic"] = k.get("hbm_bytes_per_launch")
                             out[key]["traffic_note"] = k.get("hbm_note")

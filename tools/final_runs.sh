@@ -6,13 +6,13 @@ mkdir -p $OUT
 python tools/source_hash.py > $OUT/source_hash.txt
 # 0. kernel trace + counters, serialised launches, for the workloads DESIGN.md quotes counters of -- FIRST, and put where bench.py looks
 #    for them (profiles/pmc_latest_<workload>.json in this box's copy of the tree), so that the bench lines below carry `traffic` and `counters`
-for w in cornell_pt64 forest_dof16 dragon_primary boxed_whitted dragon_whitted smallpt_pt64; do
+for w in ${PROFILED:-cornell_pt64 forest_dof16 dragon_primary boxed_whitted dragon_whitted smallpt_pt64 zaphod_whitted smallpt_whitted bokeh_dof forest_dof256}; do
   bash tools/profile_workload.sh ${TAG}_$w $w > $OUT/profile_$w.log 2>&1; cp gpurun_out/prof_${TAG}_$w/pmc.json profiles/pmc_latest_$w.json; echo "profile $w done" >> $OUT/progress.log
 done
 # 1. headline, default mode, with the CPU baseline leg
 timeout -k 10 600 python bench.py --steps 20 --warmup 2 > $OUT/bench_headline.json 2> $OUT/bench_headline.err; echo "headline done" >> $OUT/progress.log
 # 2. the other workloads (one GPU)
-for w in smallpt_pt64 boxed_whitted forest_dof16 forest_dof256 zaphod_whitted dragon_primary smallpt_whitted dragon_whitted bokeh_dof; do
+for w in ${BENCHED:-smallpt_pt64 boxed_whitted forest_dof16 forest_dof256 zaphod_whitted dragon_primary smallpt_whitted dragon_whitted bokeh_dof}; do
   timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err; echo "$w done" >> $OUT/progress.log
 done
 timeout -k 10 300 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-serial-pass --workload smallpt_4k_pt1024 > $OUT/bench_smallpt_4k_pt1024.json 2> $OUT/bench_smallpt_4k_pt1024.err; echo "4k done" >> $OUT/progress.log

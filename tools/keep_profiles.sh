@@ -4,8 +4,9 @@ set -e
 TAG=${1:-r03}
 F=gpurun_out/final_$TAG
 for f in $F/bench_*.json; do cp $f profiles/${TAG}_$(basename $f); done
-for w in cornell_pt64 forest_dof16 dragon_primary boxed_whitted dragon_whitted smallpt_pt64; do
+for w in cornell_pt64 forest_dof16 dragon_primary boxed_whitted dragon_whitted smallpt_pt64 zaphod_whitted smallpt_whitted bokeh_dof forest_dof256; do
   P=gpurun_out/prof_${TAG}_$w
+  [ -f $P/pmc.json ] || continue
   cp $P/pmc.json profiles/${TAG}_pmc_$w.json
   cp $P/pmc.json profiles/pmc_latest_$w.json
   cp $P/kernel_stats.csv profiles/${TAG}_kernel_stats_$w.csv

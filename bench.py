@@ -216,9 +216,9 @@ def main():
     # torch.distributed, and the JSON line says which transport ran.  --backend gloo (ranks sharing one GPU) stages through the host.
     gatherer = gather_ids = gather_dist = None
     transport = None
+    libgather = None
     if world > 1:
         ok = 0
-        libgather = None
         if args.backend == "nccl" and not args.torch_gather:
             try:
                 libgather = tiles.LibraryGather(rank, world, dist)
@@ -443,6 +443,11 @@ def main():
         print(json.dumps(out), flush=True)
     scene.close()
     if world > 1:
+        # every rank's work is done and seen by every other rank before a communicator goes away
+        torch.cuda.synchronize()
+        dist.barrier()
+        if libgather is not None:
+            libgather.close()
         dist.destroy_process_group()
 
 

@@ -55,6 +55,10 @@ constexpr int waves_for(int st, int n) { return (st & 2) ? (FRAY_CSG_WAVES < n ?
 #ifndef FRAY_BOUNCE_WAVES_NOKD
 #define FRAY_BOUNCE_WAVES_NOKD 5   // the variants without the KD walk need 100-106 VGPRs: 5 waves/SIMD at 94-96, 0-7 spilled (headline 111.8 -> 108.7 ms against 4 waves)
 #endif
+#ifndef FRAY_WHITTED_WAVES_KD
+#define FRAY_WHITTED_WAVES_KD 2   // k_whitted beside KD meshes (and no Cube / CSG): 211 VGPR, nothing spilled; dragon Whitted 17.1 -> 16.4 ms against 3 waves (168 VGPR, 82 spilled),
+#endif                            // 1 wave: 18.0; the Cube / CSG variants (bokeh) measure the same at 2 and 3 and stay at 3
+constexpr int whitted_waves(int st) { return waves_for(st, (st & 6) == 4 ? FRAY_WHITTED_WAVES_KD : FRAY_WHITTED_WAVES); }
 constexpr int primary_waves(int st) { return waves_for(st, kd_variant(st) ? FRAY_ANYHIT_WAVES_KD : FRAY_PRIMARY_WAVES); }
 constexpr int anyhit_waves(int st) { return waves_for(st, kd_variant(st) ? FRAY_ANYHIT_WAVES_KD : FRAY_SHADOW_WAVES); }
 
@@ -241,7 +245,7 @@ static __constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0,
 // round of the machine has a closest-hit search to run for (nearly) every lane until the frame's items are gone.
 struct WhittedArgs { DScene S; DCamera C; DFrame F; int nItems; float* rgb; uint32_t* mtWork; const uint32_t* x397; DStats* st; DCursors* cur; };
 template <int ST>
-static __global__ __launch_bounds__(256, waves_for(ST, FRAY_WHITTED_WAVES)) void k_whitted(WhittedArgs A)
+static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(WhittedArgs A)
 {
     Cnt c = zero_cnt();
     MtLong tab;

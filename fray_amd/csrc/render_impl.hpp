@@ -100,7 +100,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             if (nItems > 0 && sc->whittedNeedsRecursion) {
                 // workspace: per-thread mt19937 state columns for samples that draw more than 227 words,
                 // then x[397] of every (pixel, sample) seed
-                const int grid = persistent_grid(nItems, waves_for(ST, FRAY_WHITTED_WAVES));
+                const int grid = persistent_grid(nItems, whitted_waves(ST));
                 const size_t colBytes = ((size_t)grid * 256 * 624 * sizeof(uint32_t) + 255) / 256 * 256;
                 int rc = ensure_work(sc, colBytes + (size_t)nItems * spp * sizeof(uint32_t));
                 if (rc) return rc;

@@ -218,7 +218,7 @@ FD bool box_test_cert(const Box6& b, const LocalRay& lr, const CertRay& cr, TSta
     return res;
 }
 
-FD Box6 kd_box(const FRAY_RO DKdBox* n)
+FD Box6 kd_box(const FRAY_RO DKd* n)
 {
     Box6 b;
     b.lox = n->lo[0]; b.loy = n->lo[1]; b.loz = n->lo[2];
@@ -288,7 +288,6 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
     // triangle tests together.  Per lane the outcomes of the box tests, the order of inner nodes, leaves and triangles, and the first
     // accepted leaf are the reference's recursion, step for step.
     const FRAY_RO DKd* kd = M.kd;
-    const FRAY_RO DKdBox* kdb = M.kdBox;
     KdStack stk;
     stk.sp = 0; stk.lo = 0;
     int P = 0;                                       // the inner node being entered
@@ -314,7 +313,7 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
             bool hitNear = nearTakesFar ? yA : yB, hitFar = nearTakesFar ? yB : yA;
             const bool uncNear = nearTakesFar ? uA : uB, uncFar = nearTakesFar ? uB : uA;
             if (uncNear || uncFar) {                                // within margins of an edge: BBox::split + testIntersect as the reference computes them
-                const Box6 pb = kd_box(kdb + P);
+                const Box6 pb = kd_box(kd + P);
                 if (uncNear) {
                     Box6 cb = pb;
                     if (nearCh == 0) box_set_hi(cb, axis, split); else box_set_lo(cb, axis, split);
@@ -342,7 +341,7 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
                 const int e = kd_pop(stk);
                 next = e & 0x7fffffff; nextLeaf = (unsigned)e >> 31;
                 if (!nextLeaf) {
-                    const Box6 b = kd_box(kdb + next);
+                    const Box6 b = kd_box(kd + next);
                     st = tstate_box(b.lox, b.loy, b.loz, b.hix, b.hiy, b.hiz, s.x, s.y, s.z, rd.x, rd.y, rd.z);
                 }
                 STAMP(9);
@@ -387,7 +386,7 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
                 }
             }
             STAMP(11);
-            if (found && box_inside(kd_box(kdb + leaf), s + d * gamma)) return true;
+            if (found && box_inside(kd_box(kd + leaf), s + d * gamma)) return true;
         }
         // the leaf is done: on to the most recent pending far child (a pending leaf waits for the next round of triangle tests)
         if (stk.sp == 0) return false;
@@ -398,7 +397,7 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
             else {
                 leaf = -1;
                 P = next;
-                const Box6 b = kd_box(kdb + next);
+                const Box6 b = kd_box(kd + next);
                 st = tstate_box(b.lox, b.loy, b.loz, b.hix, b.hiy, b.hiz, s.x, s.y, s.z, rd.x, rd.y, rd.z);
             }
             STAMP(9);

@@ -114,7 +114,7 @@ def random_scene(rng, tmp, gi):
     return str(tmp / "scene.fray")
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", list(range(20)) + [45, 57])
 def test_random_scene_parity(fray, abi, oracle, gpu, tmp_path, seed):
     rng = np.random.default_rng(1000 + seed)
     gi = seed % 2
@@ -128,11 +128,22 @@ def test_random_scene_parity(fray, abi, oracle, gpu, tmp_path, seed):
     assert np.array_equal(dist, od), np.argwhere(dist != od)[:5]
     for k in ("node_tests", "tri_tests", "kd_inner_visits", "leaf_refs", "prim_tests"):
         assert st[k] == ost[k], k
-    img, _ = s.render(seed=seed)
-    ref, _ = oracle.render(s.desc, abi.MODE_RENDER, seed=seed)
-    assert np.all(np.isfinite(img))
-    r = np.sqrt(((img.astype(np.float64) - ref) ** 2).mean(axis=(0, 1)))
-    assert np.all(r <= 1e-4), r
+    # both integrators on every scene, the timed and the instrumented kernel variants of each: a scene written for the path tracer rendered by
+    # raytrace() is how a filter loop that the compiler had unrolled was caught (seeds 45, 57: k_whitted<2> wrong in a third of the pixels while
+    # its instrumented twin, every hit record and the path-traced picture were right; profiles/r03_experiments/README.md E)
+    for g in (gi, 1 - gi):
+        s.settings.gi = g
+        s.beginRender()
+        img, _ = s.render(seed=seed)
+        img2, _ = s.render(seed=seed, stats=True)
+        ref, _ = oracle.render(s.desc, abi.MODE_RENDER, seed=seed)
+        assert np.all(np.isfinite(img))
+        assert np.array_equal(img, img2), g            # same picture from both variants
+        r = np.sqrt(((img.astype(np.float64) - ref) ** 2).mean(axis=(0, 1)))
+        assert np.all(r <= 1e-4), (g, r)
+        # beyond the tolerance: at most last-place differences (the device's sin / cos are correctly rounded, glibc's are in 99.85 % of calls: a
+        # glossy sample may differ in its last bit); anything larger is a different hit somewhere
+        assert np.all(np.abs(img.astype(np.float64) - ref) <= 1e-5 * np.maximum(1.0, np.abs(ref))), g
     s.close()
 
 

@@ -59,7 +59,9 @@ def write_bmp(path, rgb):
         f.write(data)
 
 
-def random_scene(rng, tmp, gi):
+def random_scene(rng, tmp, gi, flavour=0):
+    """flavour 0: every geometry kind (the Cube / CSG kernel variants); 1: no Cube / CSG (the KD variants); 2: no Cube / CSG and no mesh big
+    enough for a KD-tree (the lean variants, with textures)"""
     W, H = int(rng.integers(40, 90)), int(rng.integers(30, 70))
     s = ["GlobalSettings {\n\tframeWidth %d\n\tframeHeight %d\n\tambientLight (0.15, 0.15, 0.2)\n\tmaxTraceDepth %d\n\twantAA %s\n\tgi %d\n\tpathsPerPixel %d\n}" %
          (W, H, int(rng.integers(2, 5)), "on" if (not gi and rng.random() < 0.3) else "off", gi, int(rng.choice([3, 9])))]   # 9 spp: four batches on four streams
@@ -74,13 +76,14 @@ def random_scene(rng, tmp, gi):
         s.append("PointLight l2 {\n\tpos (%.2f, 9, -6)\n\tpower 60\n\tcolor (0.9, 0.8, 0.7)\n}" % (rng.normal() * 4))
     s.append("Plane floor {\n\ty -2\n\tlimit 40\n}")
     s.append("Sphere ball {\n\tR 1.4\n\tO (0.2, 0.1, -0.1)\n}")
-    s.append("Cube box {\n\thalfSide 1.2\n}")
-    s.append("Cube box2 {\n\thalfSide 1.0\n\tO (0.7, 0.6, 0.5)\n}")
-    s.append("CsgMinus carved {\n\tleft box\n\tright ball\n}")
-    s.append("CsgAnd lens {\n\tleft ball\n\tright box2\n}")
-    s.append("CsgPlus both {\n\tleft carved\n\tright lens\n}")            # CsgOp of CsgOps
-    s.append("CsgMinus deep {\n\tleft both\n\tright box2\n}")             # three levels
-    (tmp / "m1.obj").write_text(random_mesh_obj(rng, int(rng.integers(30, 120)), True))
+    if flavour == 0:
+        s.append("Cube box {\n\thalfSide 1.2\n}")
+        s.append("Cube box2 {\n\thalfSide 1.0\n\tO (0.7, 0.6, 0.5)\n}")
+        s.append("CsgMinus carved {\n\tleft box\n\tright ball\n}")
+        s.append("CsgAnd lens {\n\tleft ball\n\tright box2\n}")
+        s.append("CsgPlus both {\n\tleft carved\n\tright lens\n}")            # CsgOp of CsgOps
+        s.append("CsgMinus deep {\n\tleft both\n\tright box2\n}")             # three levels
+    (tmp / "m1.obj").write_text(random_mesh_obj(rng, int(rng.integers(30, 120)) if flavour < 2 else int(rng.integers(8, 18)), True))
     (tmp / "m2.obj").write_text(random_mesh_obj(rng, int(rng.integers(4, 18)), False))
     s.append('Mesh blob {\n\tfile "m1.obj"\n\tbackfaceCulling %s\n}' % ("false" if rng.random() < 0.5 else "true"))
     s.append('Mesh shard {\n\tfile "m2.obj"\n\tbackfaceCulling false\n}')
@@ -101,7 +104,7 @@ def random_scene(rng, tmp, gi):
     s.append("Refl rough {\n\tglossiness %.2f\n\tnumSamples 3\n\tmultiplier 0.8\n}" % (0.75 + rng.random() * 0.2))
     s.append("Const flat {\n\tcolor (0.2, 0.9, 0.4)\n}")
     shaders = ["lam", "grey", "ph", "mir", "glass", "coat", "painted", "wet", "rough", "flat"] if not gi else ["lam", "grey", "mir", "glass", "painted"]
-    geoms = ["ball", "box", "carved", "lens", "blob", "shard", "both", "deep"]
+    geoms = ["ball", "box", "carved", "lens", "blob", "shard", "both", "deep"] if flavour == 0 else ["ball", "blob", "shard", "blob", "ball", "shard", "blob", "blob"]
     s.append("Node floorNode {\n\tgeometry floor\n\tshader lam\n}")
     for i, g in enumerate(geoms):
         sh = shaders[int(rng.integers(len(shaders)))]
@@ -143,6 +146,33 @@ def test_random_scene_parity(fray, abi, oracle, gpu, tmp_path, seed):
         assert np.all(r <= 1e-4), (g, r)
         # beyond the tolerance: at most last-place differences (the device's sin / cos are correctly rounded, glibc's are in 99.85 % of calls: a
         # glossy sample may differ in its last bit); anything larger is a different hit somewhere
+        assert np.all(np.abs(img.astype(np.float64) - ref) <= 1e-5 * np.maximum(1.0, np.abs(ref))), g
+    s.close()
+
+
+@pytest.mark.parametrize("seed", range(100, 112))
+def test_random_scene_parity_other_kernel_variants(fray, abi, oracle, gpu, tmp_path, seed):
+    """The scenes above all hold Cube / CSG geometry, i.e. they run the <2> / <3> kernel variants.  These hold none (even seeds: meshes with
+    KD-trees, variants <4> / <5>; odd seeds: only meshes too small for a tree, variants <8> / <9>): hit records, both integrators, both variants."""
+    rng = np.random.default_rng(1000 + seed)
+    gi = (seed // 2) % 2
+    s = fray.Scene.parseScene(random_scene(rng, tmp_path, gi, flavour=1 + seed % 2))
+    s.beginRender()
+    for stats in (True, False):
+        ids, dist, st = s.primary_hits(stats=stats)
+        oi, od, ost = oracle.render(s.desc, abi.MODE_PRIMARY_ID)
+        assert np.array_equal(ids, oi) and np.array_equal(dist, od), stats
+    if seed % 2 == 0:
+        assert ost["kd_inner_visits"] > 0
+    else:
+        assert ost["kd_inner_visits"] == 0
+    for g in (gi, 1 - gi):
+        s.settings.gi = g
+        s.beginRender()
+        img, _ = s.render(seed=seed)
+        img2, _ = s.render(seed=seed, stats=True)
+        ref, _ = oracle.render(s.desc, abi.MODE_RENDER, seed=seed)
+        assert np.array_equal(img, img2), g
         assert np.all(np.abs(img.astype(np.float64) - ref) <= 1e-5 * np.maximum(1.0, np.abs(ref))), g
     s.close()
 

@@ -374,7 +374,7 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
                     const FRAY_RO DTri32* r = lf + base + t;
                     // `rayOk32 && ...` and the branch on purpose.  Written as straight-line code (`sure_miss(...) & rayOk32`, the mask updated by a select) the loop
                     // is unrolled by two and runs 3-7 % faster -- and k_whitted<2> / k_pt_shadow<2> (Cube / CSG variants, where the mesh differs per lane)
-                    // then disagree with the oracle on some scenes (profiles/r03_experiments/README.md E; tests/test_fuzz_parity.py renders every scene with both integrators)
+                    // then render wrong pictures on some scenes (profiles/r03_experiments/README.md E; tests/test_fuzz_parity.py renders every scene with both integrators)
                     const bool miss = rayOk32 && tri_sure_miss(r->A[0], r->A[1], r->A[2], r->AB[0], r->AB[1], r->AB[2], r->AC[0], r->AC[1], r->AC[2], r->Lq, r->Cq,
                                                                s32x, s32y, s32z, d32x, d32y, d32z);
                     if (miss) bump<ST>(c.tri);           // the reference ran (and failed) its test on this one too

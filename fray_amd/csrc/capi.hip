@@ -378,7 +378,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     size_t oCsgs = A.add(csgs.data(), csgs.size() * sizeof(DCsg));
     // meshes
     std::vector<DMesh> meshes(d.n_meshes);
-    struct MeshOff { size_t tris, attrs, kd, refs, ltris, ltris32; };
+    struct MeshOff { size_t tris, attrs, kd, kdBox, refs, ltris, ltris32; };
     std::vector<MeshOff> moff(d.n_meshes);
     for (int mi = 0; mi < d.n_meshes; mi++) {
         const frayhip_mesh& m = d.meshes[mi];
@@ -421,34 +421,29 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         // KD nodes: add each node's own box.  Boxes are derived top-down exactly as BBox::split
         // does (copy parent, overwrite one coordinate).
         std::vector<DKd> kd(m.n_kdnodes);
+        std::vector<DKdBox> kdBox(m.n_kdnodes);
         if (m.n_kdnodes > 0) {
-            struct B { double lo[3], hi[3]; };
-            std::vector<B> boxes(m.n_kdnodes);
-            for (int k = 0; k < 3; k++) { boxes[0].lo[k] = m.bbox_min[k]; boxes[0].hi[k] = m.bbox_max[k]; }
+            for (int k = 0; k < 3; k++) { kdBox[0].lo[k] = m.bbox_min[k]; kdBox[0].hi[k] = m.bbox_max[k]; }
             for (int n = 0; n < m.n_kdnodes; n++) {   // parents precede children in the array
                 const frayhip_kdnode& K = m.kdnodes[n];
                 DKd& o = kd[n];
-                o.split = K.split; o.child0 = K.child0; o.parent = K.parent; o.meta = K.axis;
-                o.triBegin = K.tri_begin; o.triCount = K.tri_count; o.pad[0] = o.pad[1] = 0;
-                o.up = 0; o.psplit = 0;
-                if (K.parent >= 0) {
-                    const frayhip_kdnode& U = m.kdnodes[K.parent];
-                    o.up = U.axis | ((n - U.child0) << 2);
-                    o.psplit = U.split;
-                }
-                for (int k = 0; k < 3; k++) { o.lo[k] = boxes[n].lo[k]; o.hi[k] = boxes[n].hi[k]; }
+                o.child0 = K.child0; o.meta = K.axis;
                 if (K.axis != 3) {
+                    o.split = K.split;
                     o.meta |= (m.kdnodes[K.child0].axis == 3 ? 4 : 0) | (m.kdnodes[K.child0 + 1].axis == 3 ? 8 : 0);
-                    boxes[K.child0] = boxes[n];
-                    boxes[K.child0 + 1] = boxes[n];
-                    boxes[K.child0].hi[K.axis] = K.split;
-                    boxes[K.child0 + 1].lo[K.axis] = K.split;
+                    kdBox[K.child0] = kdBox[n];
+                    kdBox[K.child0 + 1] = kdBox[n];
+                    kdBox[K.child0].hi[K.axis] = K.split;
+                    kdBox[K.child0 + 1].lo[K.axis] = K.split;
+                } else {
+                    o.triBegin = K.tri_begin; o.triCount = K.tri_count;
                 }
             }
         }
         moff[mi].tris = A.add(tris.data(), tris.size() * sizeof(DTri));
         moff[mi].attrs = A.add(attrs.data(), attrs.size() * sizeof(DTriAttr));
         moff[mi].kd = A.add(kd.data(), kd.size() * sizeof(DKd));
+        moff[mi].kdBox = A.add(kdBox.data(), kdBox.size() * sizeof(DKdBox));
         moff[mi].refs = A.add(m.trirefs, (size_t)m.n_trirefs * sizeof(int32_t));
         std::vector<DTri> ltris((size_t)m.n_trirefs);
         for (int r = 0; r < m.n_trirefs; r++) ltris[r] = tris[m.trirefs[r]];
@@ -524,6 +519,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         meshes[mi].tris = (const FRAY_RO DTri*)(base + moff[mi].tris);
         meshes[mi].attrs = (const FRAY_RO DTriAttr*)(base + moff[mi].attrs);
         meshes[mi].kd = (const FRAY_RO DKd*)(base + moff[mi].kd);
+        meshes[mi].kdBox = (const FRAY_RO DKdBox*)(base + moff[mi].kdBox);
         meshes[mi].refs = (const FRAY_RO int32_t*)(base + moff[mi].refs);
         meshes[mi].ltris = (const FRAY_RO DTri*)(base + moff[mi].ltris);
         meshes[mi].ltris32 = (const FRAY_RO DTri32*)(base + moff[mi].ltris32);

@@ -81,25 +81,27 @@ struct DTriAttr {      // 168 B, winning triangle only
     double dNdx[3], dNdy[3];
 };
 
-struct alignas(16) DKd {   // 96 B
-    double split;      // } the 16 bytes a descending step reads
-    int32_t child0;    // }
-    int32_t meta;      // } axis (bits 0-1; 3 = leaf) | inner: bit 2+c set = child c is a leaf
-    int32_t parent;    // } the 16 bytes a climbing step reads: the parent, its axis (bits 0-1 of `up`) and split position, and
-    int32_t up;        // } which of its children this node is (bit 2 of `up`) -- enough to tell whether the parent still has its
-    double psplit;     // } second option to try, without touching the parent's record
-    int32_t triBegin, triCount, pad[2];
-    // the node's own box, exactly the coordinates BBox::split hands down (bbox.h:205-211).  A walking lane carries the ray's
-    // parameter interval against the current box (dev_boxcert.hpp), not the box: the coordinates are read when it climbs back to
-    // a node, when a leaf's hit has to pass inside(), and when a child test has to run the reference's own arithmetic.
-    double lo[3], hi[3];
+// KD nodes in the builder's depth-first order, hot and cold halves in arrays of their own: a walking lane reads 16 bytes per inner node
+// and nothing else, so eight nodes share a 128-byte line instead of one and a third (incoherent walks live on what the caches hold).
+struct alignas(16) DKd {   // 16 B: what a step of the walk reads
+    union {
+        double split;                            // inner node
+        struct { int32_t triBegin, triCount; };  // leaf: its range of DMesh::ltris / ltris32
+    };
+    int32_t child0;
+    int32_t meta;      // axis (bits 0-1; 3 = leaf) | inner: bit 2+c set = child c is a leaf
 };
+// the node's own box, exactly the coordinates BBox::split hands down (bbox.h:205-211).  A walking lane carries the ray's
+// parameter interval against the current box (dev_boxcert.hpp), not the box: the coordinates are read when a pending node is taken
+// from the stack, when a leaf's hit has to pass inside(), and when a child test has to run the reference's own arithmetic.
+struct DKdBox { double lo[3], hi[3]; };   // 48 B
 
 struct DMesh {
     double bmin[3], bmax[3];
     const FRAY_RO DTri* tris;
     const FRAY_RO DTriAttr* attrs;
     const FRAY_RO DKd* kd;
+    const FRAY_RO DKdBox* kdBox;
     const FRAY_RO int32_t* refs;
     // KD meshes: the triangle records again, one copy per leaf reference in leaf order (triBegin .. triBegin + triCount), so a
     // leaf's triangles are consecutive 128-byte records instead of an index list into `tris` (one dependent load less per triangle)

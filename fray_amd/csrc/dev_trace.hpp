@@ -11,6 +11,9 @@
 // "Which child next" is recomputed from ray.start[axis] < split, so the visiting order, the outcome of
 // every box test, the triangles tested and the first accepted leaf are exactly the reference's.
 #pragma once
+#ifndef FRAY_FILTER_STRAIGHT
+#define FRAY_FILTER_STRAIGHT 1     // see mesh_intersect's leaf loop
+#endif
 #include "dev_math.hpp"
 #include "dev_scene.hpp"
 #include "dev_sort.hpp"
@@ -218,7 +221,7 @@ FD bool box_test_cert(const Box6& b, const LocalRay& lr, const CertRay& cr, TSta
     return res;
 }
 
-FD Box6 kd_box(const FRAY_RO DKd* n)
+FD Box6 kd_box(const FRAY_RO DKdBox* n)
 {
     Box6 b;
     b.lox = n->lo[0]; b.loy = n->lo[1]; b.loz = n->lo[2];
@@ -288,6 +291,7 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
     // triangle tests together.  Per lane the outcomes of the box tests, the order of inner nodes, leaves and triangles, and the first
     // accepted leaf are the reference's recursion, step for step.
     const FRAY_RO DKd* kd = M.kd;
+    const FRAY_RO DKdBox* kdb = M.kdBox;
     KdStack stk;
     stk.sp = 0; stk.lo = 0;
     int P = 0;                                       // the inner node being entered
@@ -313,7 +317,7 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
             bool hitNear = nearTakesFar ? yA : yB, hitFar = nearTakesFar ? yB : yA;
             const bool uncNear = nearTakesFar ? uA : uB, uncFar = nearTakesFar ? uB : uA;
             if (uncNear || uncFar) {                                // within margins of an edge: BBox::split + testIntersect as the reference computes them
-                const Box6 pb = kd_box(kd + P);
+                const Box6 pb = kd_box(kdb + P);
                 if (uncNear) {
                     Box6 cb = pb;
                     if (nearCh == 0) box_set_hi(cb, axis, split); else box_set_lo(cb, axis, split);
@@ -341,7 +345,7 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
                 const int e = kd_pop(stk);
                 next = e & 0x7fffffff; nextLeaf = (unsigned)e >> 31;
                 if (!nextLeaf) {
-                    const Box6 b = kd_box(kd + next);
+                    const Box6 b = kd_box(kdb + next);
                     st = tstate_box(b.lox, b.loy, b.loz, b.hix, b.hiy, b.hiz, s.x, s.y, s.z, rd.x, rd.y, rd.z);
                 }
                 STAMP(9);
@@ -372,13 +376,22 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
                 for (int t = 0; t < m; t++) {
                     bump<ST>(c.leafRefs);
                     const FRAY_RO DTri32* r = lf + base + t;
-                    // `rayOk32 && ...` and the branch on purpose.  Written as straight-line code (`sure_miss(...) & rayOk32`, the mask updated by a select) the loop
-                    // is unrolled by two and runs 3-7 % faster -- and k_whitted<2> / k_pt_shadow<2> (Cube / CSG variants, where the mesh differs per lane)
-                    // then render wrong pictures on some scenes (profiles/r03_experiments/README.md E; tests/test_fuzz_parity.py renders every scene with both integrators)
-                    const bool miss = rayOk32 && tri_sure_miss(r->A[0], r->A[1], r->A[2], r->AB[0], r->AB[1], r->AB[2], r->AC[0], r->AC[1], r->AC[2], r->Lq, r->Cq,
-                                                               s32x, s32y, s32z, d32x, d32y, d32z);
-                    if (miss) bump<ST>(c.tri);           // the reference ran (and failed) its test on this one too
-                    else cand |= 1u << t;
+                    // Two forms of the same test.  As straight-line code (`sure_miss(...) & rayOk32`, the mask updated by a select) the compiler unrolls the loop by
+                    // two and packs the pair's FP32 operations: 3-7 % off the KD workloads.  The Cube / CSG kernel variants (flag bit 1: out-of-line calls, 100-350
+                    // spilled SGPRs next to 100-550 spilled VGPRs) keep the short circuit and the branch: with the straight-line form k_whitted<2> and k_pt_shadow<2>
+                    // rendered wrong pictures on fuzz scenes while their instrumented twins were right (profiles/r03_experiments/README.md E).  The variants without
+                    // that geometry pass 160 random KD scenes with it (both integrators, timed and instrumented kernels, hit records) and every fixture.
+                    if constexpr ((ST & 2) != 0 || !FRAY_FILTER_STRAIGHT) {
+                        const bool miss = rayOk32 && tri_sure_miss(r->A[0], r->A[1], r->A[2], r->AB[0], r->AB[1], r->AB[2], r->AC[0], r->AC[1], r->AC[2], r->Lq, r->Cq,
+                                                                   s32x, s32y, s32z, d32x, d32y, d32z);
+                        if (miss) bump<ST>(c.tri);           // the reference ran (and failed) its test on this one too
+                        else cand |= 1u << t;
+                    } else {
+                        const bool miss = tri_sure_miss(r->A[0], r->A[1], r->A[2], r->AB[0], r->AB[1], r->AB[2], r->AC[0], r->AC[1], r->AC[2], r->Lq, r->Cq,
+                                                        s32x, s32y, s32z, d32x, d32y, d32z) & rayOk32;
+                        bump<ST>(c.tri, miss ? 1ull : 0ull);
+                        cand |= (miss ? 0u : 1u) << t;
+                    }
                 }
                 STAMP(15);
                 while (cand) {
@@ -388,7 +401,7 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
                 }
             }
             STAMP(11);
-            if (found && box_inside(kd_box(kd + leaf), s + d * gamma)) return true;
+            if (found && box_inside(kd_box(kdb + leaf), s + d * gamma)) return true;
         }
         // the leaf is done: on to the most recent pending far child (a pending leaf waits for the next round of triangle tests)
         if (stk.sp == 0) return false;
@@ -399,7 +412,7 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
             else {
                 leaf = -1;
                 P = next;
-                const Box6 b = kd_box(kd + next);
+                const Box6 b = kd_box(kdb + next);
                 st = tstate_box(b.lox, b.loy, b.loz, b.hix, b.hiy, b.hiz, s.x, s.y, s.z, rd.x, rd.y, rd.z);
             }
             STAMP(9);

@@ -66,11 +66,15 @@ DCamera camera_begin_frame(const frayhip_camera& c, int W, int H)
     const double lenBC = sqrt(bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]);
     const double m = tan(rad(c.fov / 2)) / lenBC;
     const double tl[3] = {-aspect * m, +m, 1}, tr[3] = {+aspect * m, +m, 1}, bl[3] = {-aspect * m, -m, 1};
-    double S = sin(rad(c.roll)), C = cos(rad(c.roll));
+    // rotationAroundZ / X / Y (matrix.cpp:29-62) take `sin(angle)` and `cos(angle)`; the reference's build (g++ -O2) merges the pair into ONE call of
+    // glibc's sincos(), whose sine is not sin()'s in the last place for one angle in 700 (-7.93, -7.84, -19.99 degrees ...).  This file is compiled by
+    // clang, which keeps two calls: ask for sincos() by name, so that the camera is the reference's whatever compiles it.
+    double S, C;
+    sincos(rad(c.roll), &S, &C);
     const double rz[9] = {C, -S, 0, S, C, 0, 0, 0, 1};
-    S = sin(rad(c.pitch)); C = cos(rad(c.pitch));
+    sincos(rad(c.pitch), &S, &C);
     const double rx[9] = {1, 0, 0, 0, C, -S, 0, S, C};
-    S = sin(rad(c.yaw)); C = cos(rad(c.yaw));
+    sincos(rad(c.yaw), &S, &C);
     const double ry[9] = {C, 0, S, 0, 1, 0, -S, 0, C};
     double t[9], rot[9];
     matmul3(rz, rx, t);

@@ -90,9 +90,11 @@ Mat3 mat_mul(const Mat3& x, const Mat3& y)
             for (int k = 0; k < 3; k++) c.a[i][j] += x.a[i][k] * y.a[k][j];
     return c;
 }
-Mat3 rot_x(double ang) { double S = sin(ang), C = cos(ang); Mat3 r = mat_diag(1.0); r.a[1][1] = C; r.a[2][1] = S; r.a[1][2] = -S; r.a[2][2] = C; return r; }
-Mat3 rot_y(double ang) { double S = sin(ang), C = cos(ang); Mat3 r = mat_diag(1.0); r.a[0][0] = C; r.a[2][0] = -S; r.a[0][2] = S; r.a[2][2] = C; return r; }
-Mat3 rot_z(double ang) { double S = sin(ang), C = cos(ang); Mat3 r = mat_diag(1.0); r.a[0][0] = C; r.a[1][0] = S; r.a[0][1] = -S; r.a[1][1] = C; return r; }
+// sincos() by name: the reference's g++ build merges sin(angle) and cos(angle) into that call, and its sine differs from sin()'s in the last
+// place for one angle in 700
+Mat3 rot_x(double ang) { double S, C; sincos(ang, &S, &C); Mat3 r = mat_diag(1.0); r.a[1][1] = C; r.a[2][1] = S; r.a[1][2] = -S; r.a[2][2] = C; return r; }
+Mat3 rot_y(double ang) { double S, C; sincos(ang, &S, &C); Mat3 r = mat_diag(1.0); r.a[0][0] = C; r.a[2][0] = -S; r.a[0][2] = S; r.a[2][2] = C; return r; }
+Mat3 rot_z(double ang) { double S, C; sincos(ang, &S, &C); Mat3 r = mat_diag(1.0); r.a[0][0] = C; r.a[1][0] = S; r.a[0][1] = -S; r.a[1][1] = C; return r; }
 double to_rad(double deg) { return deg / 180.0 * kPI; }   // util.h:37
 
 double mat_det(const Mat3& m)   // matrix.cpp:75-83, same term order

@@ -160,11 +160,13 @@ CameraFrame cameraBeginFrame(const frayhip_camera& c, int W, int H)
     f.bottomLeft = Vec{-aspect * m, -m, 1};
     f.w = W; f.h = H;
     double S, C;
-    S = sin(rad(c.roll)); C = cos(rad(c.roll));
+    // sincos() by name: what g++ -O2 makes of the reference's `sin(angle)` / `cos(angle)` pairs (oracle/_ref imports only sincos); its sine differs
+    // from sin()'s in the last place for one angle in 700
+    sincos(rad(c.roll), &S, &C);
     double rz[9] = {C, -S, 0, S, C, 0, 0, 0, 1};     // rotationAroundZ, matrix.cpp:53-62
-    S = sin(rad(c.pitch)); C = cos(rad(c.pitch));
+    sincos(rad(c.pitch), &S, &C);
     double rx[9] = {1, 0, 0, 0, C, -S, 0, S, C};     // rotationAroundX, matrix.cpp:29-38
-    S = sin(rad(c.yaw)); C = cos(rad(c.yaw));
+    sincos(rad(c.yaw), &S, &C);
     double ry[9] = {C, 0, S, 0, 1, 0, -S, 0, C};     // rotationAroundY, matrix.cpp:41-50
     double t[9], rot[9];
     matmul3(rz, rx, t);

@@ -165,3 +165,20 @@ def test_bucket_numbering_is_the_documented_one(fray):
         x, _ = bucket_xy(1920, b)
         cols[b % 8].add(x % 8)
     assert all(len(c) == 8 for c in cols.values())
+
+
+def test_build_recipe_keeps_what_correctness_depends_on(fray):
+    """Two build facts the pictures depend on (both found the hard way): the Cube / CSG kernel variants are compiled with their SGPR
+    spills in scratch memory (with lane spills two equivalent source changes made k_whitted<2> / k_pt_shadow<2> render wrong pictures), and the host
+    code takes sine and cosine of an angle from ONE sincos() call like the reference's g++ build (clang would call sin() and cos(), whose sine
+    differs in the last place for one angle in 700).  The library must therefore import sincos and neither sin nor cos."""
+    mk = open(os.path.join(ROOT, "Makefile")).read()
+    for v in ("VARIANT_FLAGS_2", "VARIANT_FLAGS_3"):
+        line = [l for l in mk.splitlines() if l.startswith(v)]
+        assert line and "-amdgpu-spill-sgpr-to-vgpr=false" in line[0], v
+    assert "$(VARIANT_FLAGS_$*)" in mk
+    import subprocess
+    so = os.path.join(ROOT, "fray_amd", "libfrayhip.so")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+    names = {l.split()[-1].split("@")[0] for l in syms.splitlines() if l.strip()}
+    assert "sincos" in names and "sin" not in names and "cos" not in names, sorted(n for n in names if n in ("sin", "cos", "sincos"))

@@ -161,8 +161,8 @@ def reference_object_code_rate(fray_amd, abi, orc, wl, seed, W=96, H=96):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cornell_pt64", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--spp-chunk", type=int, default=0)

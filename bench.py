@@ -158,6 +158,25 @@ def reference_object_code_rate(fray_amd, abi, orc, wl, seed, W=96, H=96):
             "reference_mrays_per_s": rays / max(t_ref, 1e-6) / 1e6, "port_mrays_per_s": rays / t_port / 1e6}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N ...` without a launcher: runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <the same arguments>` as a child process (the command the driver uses), passes its output through and returns its exit
+    status.  The port is one the kernel just handed out as free."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # RCCL / tensor sharing across processes on this driver: dmabuf IPC only
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,16 +194,22 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the real multi-GPU run) or gloo (rehearsal: N ranks sharing GPU 0)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` typed like the N = 1 command: start the N ranks ourselves, as CHILD processes of a launcher that is a
+        # child of this process (which has not touched the GPU and never will: nothing is exec'ed over it), relay rank 0's JSON line and
+        # leave with the launcher's status.
+        raise SystemExit(self_launch(args.gpus))
+
     import torch
     import fray_amd
     from fray_amd import abi
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+            raise SystemExit("bench.py --gpus %d: WORLD_SIZE is 1 although RANK is set; launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if args.backend == "gloo":
         local_rank = 0                      # rehearsal on a one-GPU box: every rank drives GPU 0
     torch.cuda.set_device(local_rank)
@@ -362,6 +387,7 @@ def main():
         tf = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
         FP64_PEAK = 39.3        # TFLOP/s: MI355X vector FP64 78.6 TFLOP/s counts an FMA as two; the reference arithmetic has no FMA (one operation per lane per issue)
         out = {
+            "source_hash": src,          # of the device code that ran (tools/source_hash.py): kept measurement sets must agree on it
             "metric": "Mrays/s (closest-hit + shadow rays) at %dx%d, %dspp %s" % (
                 W, H, scene.samples_per_pixel(),
                 "primary rays" if mode == abi.MODE_PRIMARY_ID else ("path trace" if scene.settings.gi else "Whitted")),
@@ -413,6 +439,8 @@ def main():
             out["gathered_frame_equals_single_rank_frame"] = check
         if transport:
             out["config"]["gather"] = transport
+            # how many ranks RCCL itself sees in the communicator the frame was gathered on (null: the exchange did not run on RCCL)
+            out["config"]["ranks_seen_by_rccl"] = gatherer.ranks_seen_by_rccl() if gatherer is libgather and libgather is not None else None
         # Counter-derived figures (HBM traffic, VALU issue and lane utilisation) cannot be collected by this process: they come
         # from rocprofv3 --pmc passes of this same command (tools/profile_workload.sh -> profiles/pmc_latest_<workload>.json) and are
         # printed only when that profile was taken on the same device code (source hash) and workload; otherwise they stay null.

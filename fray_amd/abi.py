@@ -8,7 +8,7 @@ import ctypes as C
 i32, u32, i64, u64, f32, f64 = C.c_int32, C.c_uint32, C.c_int64, C.c_uint64, C.c_float, C.c_double
 P = C.POINTER
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, E_ARG, E_PARSE, E_NODEVICE, E_UNSUPPORTED, E_NOMEM, E_HIP = 0, -1, -2, -3, -4, -5, -6
 GEOM_PLANE, GEOM_SPHERE, GEOM_CUBE, GEOM_MESH, GEOM_CSG = range(5)
@@ -172,6 +172,7 @@ SYMBOLS = {
     "frayhip_comm_unique_id": (C.c_int, [VP]),
     "frayhip_comm_create": (C.c_int, [VP, C.c_int, C.c_int, P(VP)]),
     "frayhip_comm_from_nccl": (C.c_int, [VP, C.c_int, C.c_int, P(VP)]),
+    "frayhip_comm_ranks": (C.c_int, [VP]),
     "frayhip_comm_destroy": (None, [VP]),
     "frayhip_gather_buckets": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "frayhip_to_rgb32": (C.c_int, [VP, VP, C.c_int]),

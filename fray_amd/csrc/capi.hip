@@ -273,7 +273,7 @@ std::string validate_desc(const frayhip_scene_desc& d)
                 const frayhip_kdnode& n = m.kdnodes[k];
                 if (n.parent < -1 || n.parent >= k || (k == 0) != (n.parent == -1)) return bad("KD parent link is not a tree in mesh", i);
                 // the walk's stack of pending children holds one entry per level (dev_trace.hpp); the reference's builder stops at 65 (constants.h:39)
-                if (k > 0 && (depth[k] = depth[n.parent] + 1) >= FRAY_KD_MAX_DEPTH) return bad("KD tree deeper than the walk's stack (72 levels) in mesh", i);
+                if (k > 0 && (depth[k] = depth[n.parent] + 1) >= FRAY_KD_MAX_DEPTH) return bad(("KD tree deeper than the walk's stack (" + std::to_string(FRAY_KD_MAX_DEPTH) + " levels) in mesh").c_str(), i);
                 if (n.axis == 3) {
                     if (n.tri_begin < 0 || n.tri_count < 0 || (int64_t)n.tri_begin + n.tri_count > m.n_trirefs) return bad("KD leaf range out of bounds in mesh", i);
                 } else if (n.axis >= 0 && n.axis <= 2) {
@@ -349,7 +349,8 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         nodes[i].xfClass = i;
         nodes[i].pad = 0;
         for (int j = 0; j < i; j++)
-            if (!memcmp(d.nodes[j].T.offset, n.T.offset, sizeof n.T.offset) && !memcmp(d.nodes[j].T.invM, n.T.invM, sizeof n.T.invM)) {
+            if (!memcmp(d.nodes[j].T.offset, n.T.offset, sizeof n.T.offset) && !memcmp(d.nodes[j].T.invM, n.T.invM, sizeof n.T.invM) &&
+                !memcmp(d.nodes[j].T.m, n.T.m, sizeof n.T.m)) {
                 nodes[i].xfClass = nodes[j].xfClass;
                 break;
             }

@@ -32,6 +32,8 @@ struct Rccl {
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     std::string why;
 };
 
@@ -62,6 +64,8 @@ Rccl* rccl()
         r.Send = (decltype(r.Send))sym("ncclSend");
         r.Recv = (decltype(r.Recv))sym("ncclRecv");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
+        r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
     });
     return r.why.empty() ? &r : nullptr;
 }
@@ -124,7 +128,13 @@ int frayhip_comm_create(const void* id128, int rank, int world, frayhip_comm** o
 int frayhip_comm_from_nccl(void* nccl_comm, int rank, int world, frayhip_comm** out)
 {
     if (!out || !nccl_comm || world < 1 || rank < 0 || rank >= world) { set_error("frayhip_comm_from_nccl: bad argument"); return FRAYHIP_E_ARG; }
-    if (!rccl()) { set_error("frayhip_comm_from_nccl: RCCL is not available on this host"); return FRAYHIP_E_UNSUPPORTED; }
+    Rccl* R = rccl();
+    if (!R) { set_error("frayhip_comm_from_nccl: RCCL is not available on this host"); return FRAYHIP_E_UNSUPPORTED; }
+    // the communicator's own idea of its size and of this rank must be the caller's: a gather with the wrong world deadlocks or scatters
+    int n = 0, me = -1;
+    NCCL_TRY(R->CommCount((ncclComm_t)nccl_comm, &n));
+    NCCL_TRY(R->CommUserRank((ncclComm_t)nccl_comm, &me));
+    if (n != world || me != rank) { set_error("frayhip_comm_from_nccl: the communicator says rank " + std::to_string(me) + " of " + std::to_string(n) + ", the caller rank " + std::to_string(rank) + " of " + std::to_string(world)); return FRAYHIP_E_ARG; }
     frayhip_comm* c = new frayhip_comm();
     c->comm = (ncclComm_t)nccl_comm; c->rank = rank; c->world = world; c->owned = false;
     *out = c;
@@ -203,6 +213,18 @@ int frayhip_gather_buckets(frayhip_comm* c, float* d_frame, int width, int heigh
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->stageFree, stream));
     return FRAYHIP_OK;
+}
+
+// How many ranks RCCL itself sees in this communicator (ncclCommCount); a world-of-one communicator made without RCCL reports 1.
+int frayhip_comm_ranks(frayhip_comm* c)
+{
+    if (!c) { set_error("frayhip_comm_ranks: null argument"); return FRAYHIP_E_ARG; }
+    if (!c->comm) return c->world;
+    Rccl* R = rccl();
+    if (!R) { set_error("frayhip_comm_ranks: RCCL is not available on this host"); return FRAYHIP_E_UNSUPPORTED; }
+    int n = 0;
+    NCCL_TRY(R->CommCount(c->comm, &n));
+    return n;
 }
 
 // Can this host exchange through RCCL at all?  Every rank asks before any rank enters ncclCommInitRank (which blocks until all

@@ -6,10 +6,10 @@
 //    read (gnormal, A, ABxAC, AC, AB: SURVEY 8(a) a9), padded to 128 B so a lane fetches it with
 //    eight aligned 16-byte loads; shading attributes (pre-gathered corner normals / uvs, dNdx,
 //    dNdy) live in a separate array touched only for the winning triangle;
-//  * KD nodes are 96-byte records {split, child0, axis | parent, its axis and split | leaf range | the node's own box}: a
-//    stackless walk reads the box when it climbs back to a node (the reference recomputes child
-//    boxes by BBox::split on the way down, mesh.cpp:373-376, and gets the parent box back from its
-//    call stack);
+//  * KD nodes are split into a 16-byte hot record {split | leaf range, child0, axis + leaf flags} (DKd: all a step of the walk reads) and
+//    a 48-byte box (DKdBox: read when a pending child is taken from the walk's stack, when a leaf's hit has to pass inside(), and when a
+//    child test falls within the margins of the certified box test; the reference recomputes child boxes by BBox::split on the way down,
+//    mesh.cpp:373-376);
 //  * nodes / lights / shaders / textures are tiny tables indexed wave-uniformly, so they are
 //    fetched through the scalar cache.
 #pragma once
@@ -44,7 +44,7 @@ struct DTri;
 struct DNode {
     DXform T;
     int32_t geomKind, geomIndex, shader, bumpTex;
-    int32_t xfClass;      // index of the first node whose {offset, invM} is bitwise equal: nodes of one class see the
+    int32_t xfClass;      // index of the first node whose {offset, m, invM} are bitwise equal: nodes of one class see the
                           // same local ray, so it is computed once per ray (e.g. the 7 untransformed Cornell-box meshes)
     // A mesh WITHOUT a KD-tree (Mesh::intersect's brute-force loop, mesh.cpp:157-161: at most 20 triangles) carries a
     // copy of what its root box test and triangle loop read, so neither needs a second dependent load through DMesh:

@@ -3,13 +3,13 @@
 // Plane / Sphere (geometry.cpp:30-83), RectLight::intersect (lights.cpp:79-103) and
 // Mesh::intersect with its KD-tree (mesh.cpp:144-165, 357-394).
 //
-// The KD walk is stackless: the reference recurses (depth reaches 65 on teapot_hires) and carries
-// the child boxes on its call stack.  Here a lane carries the ray's parameter interval against the
-// current box ({t0, n2, t1}, dev_boxcert.hpp) instead of the box: a child's interval follows from its
-// parent's with one multiplication, and it decides BBox::testIntersect for the child outright except
-// within margins of an edge, where the lane reads the node's box and runs the reference's arithmetic.
-// "Which child next" is recomputed from ray.start[axis] < split, so the visiting order, the outcome of
-// every box test, the triangles tested and the first accepted leaf are exactly the reference's.
+// The KD walk (mesh_intersect) is a while-while loop over an explicit per-lane stack of pending far children (KdStack: the 16 most recent
+// entries in LDS, older ones in scratch); the reference recurses (depth reaches 65 on teapot_hires) and carries the child boxes on its call
+// stack.  Here a lane carries the ray's parameter interval against the current box ({t0, n2, t1}, dev_boxcert.hpp) instead of the box: a
+// child's interval follows from its parent's with one multiplication, and it decides BBox::testIntersect for the child outright except
+// within margins of an edge, where the lane reads the node's box and runs the reference's arithmetic.  Both children are tested when a node
+// is entered (the tests are pure functions of the ray); "which child first" is ray.start[axis] < split, so the visiting order, the outcome
+// of every box test, the triangles tested and the first accepted leaf are exactly the reference's.
 #pragma once
 #ifndef FRAY_FILTER_STRAIGHT
 #define FRAY_FILTER_STRAIGHT 1     // see mesh_intersect's leaf loop

@@ -28,7 +28,9 @@
 // lambda2 + lambda3 > 1, i.e. lambda1 < 0 (triangle.cpp:91) unless an earlier test already returned false.
 // A record whose operands are outside the range where FP32 products neither overflow nor lose their bits to underflow
 // (|coordinate - ref| > 2^30, L < 2^-40), or whose ABcrossAC is not the cross product of its AB and AC, carries E = +inf: never
-// rejected here.  Products that underflow add at most 20 * 2^-126 (flushed or not) where E >= 2^-94.  A ray is only filtered when |s - ref| <= 1e9 per component.  Backface culling (mesh.cpp:106) is left to the reference's
+// rejected here.  Products that underflow add at most 20 * 2^-126 (flushed or not) where E >= 2^-94.  A ray is only filtered when |s - ref| <= 1e9 per component.
+// PRECONDITION |d|_inf <= 1 (the bound's terms |H| L and L^2 are what products with a direction component of magnitude <= 1 can reach): every
+// caller passes a local ray whose direction Node::intersect has normalised (Transform::untransformDir, matrix.cpp:158-161), and the harness does too.  Backface culling (mesh.cpp:106) is left to the reference's
 // arithmetic: a culled triangle that is not rejected here costs time, never a wrong answer.
 // tests/native/tricert_check.cpp runs this header on the host against the reference's arithmetic over adversarial rays
 // (edges, vertices, grazing rays, slivers, far origins, huge and tiny triangles).

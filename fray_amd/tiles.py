@@ -81,6 +81,13 @@ class LibraryGather:
             raise _scene.FrayError(rc, _scene.lib.frayhip_last_error().decode())
         return frame
 
+    def ranks_seen_by_rccl(self):
+        """ncclCommCount of the communicator the gathers run on (frayhip_comm_ranks)."""
+        n = _scene.lib.frayhip_comm_ranks(self._comm)
+        if n < 0:
+            raise _scene.FrayError(n, _scene.lib.frayhip_last_error().decode())
+        return n
+
     def close(self):
         if self._comm:
             _scene.lib.frayhip_comm_destroy(self._comm)

@@ -18,7 +18,10 @@
 extern "C" {
 #endif
 
-#define FRAYHIP_ABI_VERSION 2
+/* 3: the bucket numbering changed meaning (bucket b sits in column (b % BW + FRAYHIP_BUCKET_SKEW * row) % BW, see frayhip_bucket_xy): a host built
+ * against version 2 that packs or unpacks buckets itself (row-major, bx = b % BW) would scatter tiles to the wrong places, so it must not pass the
+ * version check.  frayhip_bucket_xy and frayhip_comm_available were added with the same change. */
+#define FRAYHIP_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------------------------ */
 enum {
@@ -319,7 +322,10 @@ int  frayhip_unpack_buckets_device(const float* d_packed, float* d_frame, int wi
  *   frayhip_comm_unique_id   rank 0 obtains the 128-byte ncclUniqueId and hands it to the other ranks by whatever
  *                            means the host has (MPI, a file, torch.distributed, a socket)
  *   frayhip_comm_create      every rank, with the same id; world == 1 needs no id and no RCCL
- *   frayhip_comm_from_nccl   wraps an ncclComm_t the host already owns (not destroyed by frayhip_comm_destroy)
+ *   frayhip_comm_from_nccl   wraps an ncclComm_t the host already owns (not destroyed by frayhip_comm_destroy); FRAYHIP_E_ARG when the
+ *                            communicator's own size / rank (ncclCommCount / ncclCommUserRank) are not the caller's
+ *   frayhip_comm_ranks       the number of ranks RCCL itself sees in the communicator (ncclCommCount; 1 for a world of one made without
+ *                            RCCL), negative error code on failure: what a host prints to show that the exchange really spans N GPUs
  *   frayhip_comm_available   1 when RCCL can be bound in this process, 0 otherwise: frayhip_comm_create blocks inside
  *                            ncclCommInitRank until EVERY rank has entered it, so the ranks agree on this first
  * RCCL is bound at run time (an RCCL the process already holds is used, none is loaded beside it): FRAYHIP_E_UNSUPPORTED
@@ -331,6 +337,7 @@ int  frayhip_comm_available(void);
 int  frayhip_comm_unique_id(void* id128);
 int  frayhip_comm_create(const void* id128, int rank, int world, frayhip_comm** out);
 int  frayhip_comm_from_nccl(void* nccl_comm, int rank, int world, frayhip_comm** out);
+int  frayhip_comm_ranks(frayhip_comm* c);
 void frayhip_comm_destroy(frayhip_comm* c);
 int  frayhip_gather_buckets(frayhip_comm* c, float* d_frame, int width, int height, int channels, int root, void* hip_stream);
 

@@ -68,16 +68,16 @@ def test_comm_available_reports_rccl(fray, gpu):
 def test_mgpu_example_with_one_rank_writes_the_single_gpu_picture(tmp_path):
     """examples/fray_render_mgpu (one process per GPU, frayhip_gather_buckets as the exchange) with N = 1 must write, byte for byte,
     the BMP examples/fray_render writes: the fork / communicator / gather plumbing around the same frame."""
-    import subprocess
     one, many = os.path.join(ROOT, "examples", "fray_render"), os.path.join(ROOT, "examples", "fray_render_mgpu")
     if not (os.path.exists(one) and os.path.exists(many)):
         pytest.fail("examples are not built (make)")
     scene = os.path.join(ROOT, "scenes", "cornell_box.fray")
     a, b = tmp_path / "one.bmp", tmp_path / "mgpu.bmp"
-    r1 = subprocess.run([one, scene, str(a), "96", "64", "4"], capture_output=True, text=True, timeout=300)
-    assert r1.returncode == 0, r1.stderr
-    r2 = subprocess.run([many, scene, str(b), "96", "64", "4", "1"], capture_output=True, text=True, timeout=300)
-    assert r2.returncode == 0, r2.stdout + r2.stderr
+    # both programs are children of the fork server (conftest.py), not of this process, which other tests have left GPU-initialised
+    l1 = run_in_clean_child([one, scene, str(a), "96", "64", "4"], str(tmp_path / "one.log"), timeout=300)
+    assert "[exit code 0]" in l1, l1
+    l2 = run_in_clean_child([many, scene, str(b), "96", "64", "4", "1"], str(tmp_path / "mgpu.log"), timeout=300)
+    assert "[exit code 0]" in l2, l2
     assert open(a, "rb").read() == open(b, "rb").read()
 
 

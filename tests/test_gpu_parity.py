@@ -627,15 +627,15 @@ def test_camera_and_settings_can_change_between_frames(fray, abi, oracle, gpu):
 
 def test_cxx_host_example_renders_like_the_python_path(fray, gpu, tmp_path):
     """examples/fray_render: a C++ main() over the C ABI (no Python, no torch in that process)."""
-    import subprocess
+    from conftest import run_in_clean_child
     exe = os.path.join(ROOT, "examples", "fray_render")
     if not os.path.exists(exe):
         pytest.fail("examples/fray_render is not built (make)")
     out = tmp_path / "c.bmp"
-    r = subprocess.run([exe, os.path.join(ROOT, "scenes", "cornell_box.fray"), str(out), "64", "48", "4"],
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr
-    assert "Render took" in r.stdout and "Exited cleanly" in r.stdout
+    # started from the fork server, not from this (GPU-initialised) process: conftest.py
+    log = run_in_clean_child([exe, os.path.join(ROOT, "scenes", "cornell_box.fray"), str(out), "64", "48", "4"], str(tmp_path / "c.log"), timeout=300)
+    assert "[exit code 0]" in log, log
+    assert "Render took" in log and "Exited cleanly" in log
     s = open_scene(fray, "cornell_box.fray", 64, 48, numPaths=4)
     s.beginRender()
     img, _ = s.render(seed=42)

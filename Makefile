@@ -32,14 +32,8 @@ fray_amd/csrc/%.o: fray_amd/csrc/%.hip $(HIP_HDR)
 
 # -Rpass-analysis=kernel-resource-usage: registers, spills, scratch and LDS of every kernel of the variant (kept
 # next to the object; `make resources` gathers them into profiles/)
-# The Cube / CSG kernel variants (flag bit 1: sixteen out-of-line CsgOp levels, 100-350 spilled SGPRs beside 100-550 spilled VGPRs) are compiled
-# with their SGPR spills going to scratch memory instead of VGPR lanes: with lane spills two unrelated source changes (a filter loop the compiler
-# unrolled; KD nodes split into two arrays) made k_whitted<2> / k_pt_shadow<2> render wrong pictures while their instrumented twins were right,
-# and both are right with this flag (profiles/r03_experiments/README.md E, H).  The other variants have no calls and keep the default.
-VARIANT_FLAGS_2 = -mllvm -amdgpu-spill-sgpr-to-vgpr=false
-VARIANT_FLAGS_3 = -mllvm -amdgpu-spill-sgpr-to-vgpr=false
 fray_amd/csrc/variant%.o: fray_amd/csrc/render_variant.hip $(HIP_HDR)
-	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) $(VARIANT_FLAGS_$*) -DFRAY_ST=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> fray_amd/csrc/variant$*.resources.txt || (cat fray_amd/csrc/variant$*.resources.txt; false)
+	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -DFRAY_ST=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> fray_amd/csrc/variant$*.resources.txt || (cat fray_amd/csrc/variant$*.resources.txt; false)
 
 fray_amd/libfrayhip.so: $(HOST_OBJ) $(HIP_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl

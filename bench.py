@@ -36,6 +36,9 @@ WORKLOADS = {
     "smallpt_whitted": ("smallpt.fray", 1920, 1080, dict(gi=0, wantAA=0), "smallpt.fray 1920x1080 1spp Whitted (mirror + glass recursion: k_whitted)"),
     "bokeh_dof": ("hw10/bokeh.fray", 640, 480, dict(), "hw10/bokeh.fray 640x480 DOF 45spp Whitted as shipped (Cube - Cube CSG floor, Layered over a mirror, Phong mesh: k_whitted, CSG variant)"),
     "dragon_whitted": ("hw9/dragon.fray", 1920, 1080, dict(wantAA=0), "hw9/dragon.fray 1920x1080 1spp Whitted (glossy floor: k_whitted)"),
+    # a scene of this repository (tests/scenes): CsgOp trees three levels deep over a CSG slab floor, a mesh operand, transformed nodes
+    "csg_nested_whitted": ("../tests/scenes/csg_nested.fray", 960, 720, dict(wantAA=0), "tests/scenes/csg_nested.fray 960x720 1spp Whitted (nested CsgOps: k_wh_shade / k_wh_visible, CSG variants)"),
+    "csg_nested_pt16": ("../tests/scenes/csg_nested.fray", 960, 720, dict(gi=1, numPaths=16), "tests/scenes/csg_nested.fray 960x720 16spp path trace (nested CsgOps: k_pt_bounce / k_pt_shadow, CSG variants)"),
 }
 
 

@@ -30,7 +30,7 @@
 // Envelope of the device CSG code (dev_trace.hpp csg_intersect); frayhip_scene_create checks scenes against it.
 #define FRAY_CSG_MAX 30   // intersections kept per operand: the reference's own limit (geometry.cpp:144)
 #ifndef FRAY_CSG_DEPTH
-#define FRAY_CSG_DEPTH 16 // CsgOp levels the device unrolls: 1 = operands are plain geometries; deeper scenes are rejected at upload
+#define FRAY_CSG_DEPTH 16 // CsgOp activations the device's stack holds (dev_trace.hpp csg_intersect): 1 = operands are plain geometries; deeper scenes are rejected at upload
 #endif
 
 // The KD walk's stack of pending children (dev_trace.hpp): the 16 most recent entries of a lane in LDS, older ones in scratch; deeper trees are

@@ -74,19 +74,11 @@ FD void finalize_hit(const DScene& S, const HitRec& h, V3 o, V3 d, bool needUV, 
     info.dNdy = v3(0, 0, 0);
     info.u = 0; info.v = 0;
     if ((ST & 2) && N.geomKind == 2) {
-        GHit g;
-        cube_intersect(S.cubes[N.geomIndex], ls, ldir, g);       // same arithmetic as during the search
-        ipl = g.ip;
-        prim_attributes(S, 2, N.geomIndex, ipl, g.code, 0, 0, needUV, needBump, nl, info);
+        ipl = h.ipl;                                              // Cube::intersect's own ip and side, kept by closest_hit
+        prim_attributes(S, 2, N.geomIndex, ipl, h.tri, 0, 0, needUV, needBump, nl, info);
     } else if ((ST & 2) && N.geomKind == 4) {
-        const FRAY_RO DCsg& G = S.csgs[N.geomIndex];
-        GHit g;
-        bool env = false;
-        Cnt dummy;
-        dummy.envelope = 0;
-        csg_intersect<(ST & 2), FRAY_CSG_DEPTH - 1>(S, G, ls, ldir, ray_rdir(ldir), g, env, dummy);
-        ipl = g.ip;
-        prim_attributes(S, g.leafKind, g.leafIndex, ipl, g.code, g.l2, g.l3, needUV, needBump, nl, info);
+        ipl = h.ipl;                                              // the winning intersection of CsgOp::intersect as its leaf geometry reported it
+        prim_attributes(S, h.leafKind, h.leafIndex, ipl, h.tri, h.l2, h.l3, needUV, needBump, nl, info);
     } else {
         double l2 = h.l2, l3 = h.l3;
         if (BARY && N.geomKind == 3) {

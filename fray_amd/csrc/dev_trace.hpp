@@ -44,6 +44,11 @@ struct HitRec {
     double dist;    // world distance (Node::intersect's recomputed dist)
     double t;       // local ray parameter: plane `scaling`, sphere `dist`, triangle gamma
     double l2, l3;  // barycentrics (meshes)
+    // Cube / CSG nodes only (the <ST & 2> kernel variants; dead code elsewhere): the winning intersection as its geometry reported it --
+    // the local hit point (not ls + ld t for these two) and, for a CsgOp, the plain geometry at the bottom of the tree that produced it --
+    // so that finalize_hit does not have to run CsgOp::intersect a second time to learn them.
+    V3 ipl;
+    int leafKind, leafIndex;
 };
 
 struct Box6 { double lox, loy, loz, hix, hiy, hiz; };
@@ -499,90 +504,120 @@ FD bool prim_intersect(const DScene& S, int kind, int index, V3 s, V3 d, V3 rd, 
 }
 
 
-template <int ST, int LEVELS>
-FD bool csg_intersect(const DScene& S, const FRAY_RO DCsg& G, V3 s, V3 d, V3 rd, GHit& win, bool& envelope, Cnt& c);
-// A CsgOp operand that is itself a CsgOp: an out-of-line call per nesting level (inlining the levels into one another
-// would copy the whole geometry code once per level and call site).
-template <int ST, int LEVELS>
-__device__ __attribute__((noinline)) bool csg_child(const DScene& S, int index, V3 s, V3 d, V3 rd, GHit& h, bool& envelope, Cnt& c)
+// CsgOp::intersect (geometry.cpp:139-194), nested CsgOps included, as ONE loop over an explicit stack of activations -- the reference
+// recurses through the Geometry virtual (geometry.cpp:146) without bound; here the nesting bound is the depth of the stack
+// (FRAY_CSG_DEPTH; frayhip_scene_create rejects deeper trees), and there is one copy of the geometry code (prim_intersect) and no call.
+//
+// One activation = one CsgOp asked about one ray start.  findAllIntersections keeps up to 30 intersections per operand
+// (geometry.cpp:144-152); per activation only their distances are kept, ordered exactly as libstdc++'s std::sort orders them
+// (dev_sort.hpp: the sort is not stable, and coincident faces of two operands are equally distant).  The winning intersection's full
+// record is then derived again by a second pass over that operand's chain up to it -- the same calls on the same rays, so the same
+// bits -- which keeps an activation at ~600 bytes of scratch.  The machine:
+//   ASK      the current activation wants the next intersection of its current operand from `start`: a plain geometry is intersected
+//            here (all lanes of the wave that stand at ASK do it together), a CsgOp operand pushes a new activation;
+//   DELIVER  an answer (found / not found) goes to the activation on top: pass 0 records the distance and asks again, or moves on to
+//            the right operand, or -- both chains done -- sorts, walks the in / out states and starts pass 1 (or answers "no hit");
+//            pass 1 counts up to the winner and answers with it.  An answer pops the activation and is delivered to the one below.
+// Work counters: pass 1 repeats calls pass 0 counted, so everything below an activation in pass 1 is not counted (`quietAt`).
+struct CsgFrame {
+    double s[3];          // the ray start this CsgOp was asked about
+    double winDist;
+    int32_t csg;          // index into DScene::csgs
+    unsigned char n, k, cnt0, cnt1, winOp, winK, pass, op;
+};
+template <int ST>
+FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win, bool& envelope, Cnt& c)
 {
-    return csg_intersect<ST, LEVELS>(S, S.csgs[index], s, d, rd, h, envelope, c);
-}
-
-// operand->intersect(ray, info) of a CsgOp whose own subtree has LEVELS more CsgOp levels available.
-// The reference recurses through the Geometry virtual (geometry.cpp:146); here the recursion is
-// unrolled by the template parameter.
-template <int ST, int LEVELS>
-FD bool operand_intersect(const DScene& S, int kind, int index, V3 s, V3 d, V3 rd, GHit& h, bool& envelope, Cnt& c)
-{
-    if (kind == 4) {
-        if constexpr (LEVELS > 0) return csg_child<ST, LEVELS - 1>(S, index, s, d, rd, h, envelope, c);
-        envelope = true;          // unreachable: frayhip_scene_create rejects deeper trees
-        return false;
-    }
-    const bool ok = prim_intersect<ST>(S, kind, index, s, d, rd, h, c);
-    h.leafKind = kind; h.leafIndex = index;
-    return ok;
-}
-
-// CsgOp::intersect (geometry.cpp:139-194).  The winner carries the leaf geometry that produced it.
-// findAllIntersections keeps up to 30 intersections per operand (geometry.cpp:144-152); per level only their distances
-// are kept, ordered exactly as libstdc++'s std::sort orders them (dev_sort.hpp: the sort is not stable, and coincident
-// faces of two operands are equally distant).  The winning intersection's full record is then derived again by a second
-// pass over that operand's chain up to it -- the same calls on the same rays, so the same bits -- which keeps a level's
-// scratch at 540 bytes.  Both passes share ONE call site of operand_intersect.
-template <int ST, int LEVELS>
-FD bool csg_intersect(const DScene& S, const FRAY_RO DCsg& G, V3 s, V3 d, V3 rd, GHit& win, bool& envelope, Cnt& c)
-{
-    double dist[2 * FRAY_CSG_MAX];
-    unsigned char order[2 * FRAY_CSG_MAX];
-    int n = 0, cnt[2] = {0, 0};
-    int winOp = 0, winK = 0;
-    double winDist = 0;
-    Cnt quiet = c;                                                          // pass 1 repeats work that pass 0 counted
-    for (int pass = 0; pass < 2; pass++) {
-        for (int op = pass == 0 ? 0 : winOp; op < (pass == 0 ? 2 : winOp + 1); op++) {   // findAllIntersections, geometry.cpp:139-159
+    CsgFrame fr[FRAY_CSG_DEPTH];
+    double dist[FRAY_CSG_DEPTH][2 * FRAY_CSG_MAX];
+    unsigned char order[FRAY_CSG_DEPTH][2 * FRAY_CSG_MAX];
+    int level = 0, quietAt = -1;
+    V3 start = s;
+    fr[0].s[0] = s.x; fr[0].s[1] = s.y; fr[0].s[2] = s.z;
+    fr[0].csg = rootCsg; fr[0].n = fr[0].k = fr[0].cnt0 = fr[0].cnt1 = fr[0].winOp = fr[0].winK = fr[0].pass = fr[0].op = 0;
+    for (;;) {
+        // ---- ASK
+        bool ok;
+        GHit h;
+        {
+            const FRAY_RO DCsg& G = S.csgs[fr[level].csg];
+            const int op = fr[level].op;
             const int kind = op == 0 ? G.leftKind : G.rightKind, index = op == 0 ? G.leftIndex : G.rightIndex;
-            V3 start = s;
-            GHit h;
-            int k = 0;
-            while (operand_intersect<ST, LEVELS>(S, kind, index, start, d, rd, h, envelope, pass == 0 ? c : quiet)) {
-                if (pass == 0) {
-                    if (k == FRAY_CSG_MAX) break;                           // `counter-- > 0`: the 31st intersection is found and dropped
-                    dist[n] = k > 0 ? length(h.ip - s) : h.dist;            // geometry.cpp:155-156
-                    order[n] = (unsigned char)n;
-                    n++;
-                } else if (k == winK) {
-                    win = h;
-                    win.dist = winDist;
-                    return true;
+            if (kind == 4) {
+                if (level + 1 < FRAY_CSG_DEPTH) {
+                    level++;
+                    fr[level].s[0] = start.x; fr[level].s[1] = start.y; fr[level].s[2] = start.z;
+                    fr[level].csg = index; fr[level].n = fr[level].k = fr[level].cnt0 = fr[level].cnt1 = fr[level].winOp = fr[level].winK = fr[level].pass = fr[level].op = 0;
+                    continue;
                 }
-                k++;
-                start = h.ip + d * 1e-6;
+                envelope = true;          // unreachable: frayhip_scene_create rejects deeper trees
+                ok = false;
+            } else {
+                if constexpr ((ST & 1) != 0) {
+                    const Cnt keep = c;
+                    ok = prim_intersect<ST>(S, kind, index, start, d, rd, h, c);
+                    if (quietAt >= 0) { const unsigned env = c.envelope; c = keep; c.envelope = env; }
+                } else {
+                    ok = prim_intersect<ST>(S, kind, index, start, d, rd, h, c);
+                }
+                h.leafKind = kind; h.leafIndex = index;
             }
-            if (pass == 0) cnt[op] = k;
         }
-        if (pass == 1) return false;                                        // unreachable: pass 0 found this intersection
-        StdSort sorter{dist, order};
-        sorter.sort(n);
-        bool inL = (cnt[0] & 1) == 1, inR = (cnt[1] & 1) == 1;
-        auto bop = [&](bool l, bool r) { return G.op == 0 ? (l || r) : (G.op == 1 ? (l && r) : (l && !r)); };
-        const bool cur = bop(inL, inR);
-        bool any = false;
-        for (int i = 0; i < n && !any; i++) {
-            const int e = order[i], op = e < cnt[0] ? 0 : 1;
-            if (op == 0) inL = !inL; else inR = !inR;
-            if (bop(inL, inR) != cur) { any = true; winOp = op; winK = op == 0 ? e : e - cnt[0]; winDist = dist[e]; }
+        // ---- DELIVER, until an activation asks again
+        for (;;) {
+            CsgFrame& F = fr[level];
+            const V3 fs = v3(F.s[0], F.s[1], F.s[2]);
+            bool answer = false;                                  // this activation is done: (ok, h) is ITS answer
+            if (ok && F.pass == 0 && F.k == FRAY_CSG_MAX) ok = false;          // `counter-- > 0`: the 31st intersection is found and dropped
+            if (ok) {
+                if (F.pass == 0) {
+                    dist[level][F.n] = F.k > 0 ? length(h.ip - fs) : h.dist;   // geometry.cpp:155-156
+                    order[level][F.n] = F.n;
+                    F.n++; F.k++;
+                    start = h.ip + d * 1e-6;
+                } else if (F.k == F.winK) {
+                    h.dist = F.winDist;
+                    answer = true;
+                } else {
+                    F.k++;
+                    start = h.ip + d * 1e-6;
+                }
+            } else if (F.pass == 0) {
+                if (F.op == 0) { F.cnt0 = F.k; F.op = 1; F.k = 0; start = fs; }
+                else {
+                    F.cnt1 = F.k;
+                    const FRAY_RO DCsg& G = S.csgs[F.csg];
+                    const int n = F.n, c0 = F.cnt0;
+                    StdSort sorter{dist[level], order[level]};
+                    sorter.sort(n);
+                    bool inL = (c0 & 1) == 1, inR = (F.cnt1 & 1) == 1;
+                    auto bop = [&](bool l, bool r) { return G.op == 0 ? (l || r) : (G.op == 1 ? (l && r) : (l && !r)); };
+                    const bool cur = bop(inL, inR);
+                    bool any = false;
+                    for (int i = 0; i < n && !any; i++) {
+                        const int e = order[level][i], o = e < c0 ? 0 : 1;
+                        if (o == 0) inL = !inL; else inR = !inR;
+                        if (bop(inL, inR) != cur) { any = true; F.winOp = (unsigned char)o; F.winK = (unsigned char)(o == 0 ? e : e - c0); F.winDist = dist[level][e]; }
+                    }
+                    if (!any) answer = true;                      // (false, -)
+                    else {
+                        F.pass = 1; F.op = F.winOp; F.k = 0; start = fs;
+                        if (quietAt < 0) quietAt = level;
+                    }
+                }
+            } else answer = true;                                 // unreachable: pass 0 found this intersection
+            if (!answer) break;
+            if (quietAt == level) quietAt = -1;
+            if (level == 0) { win = h; return ok; }
+            level--;
         }
-        if (!any) return false;
     }
-    return false;
 }
 
 // Geometry part of Node::intersect for node N on the local ray; on a hit returns the local
 // intersection point and fills t / tri / l2 / l3.
 template <int ST>
-FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, LocalRay& lr, V3& ipl, double& t, int& tri, double& l2, double& l3, Cnt& c)
+FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, LocalRay& lr, V3& ipl, double& t, int& tri, double& l2, double& l3, int& leafKind, int& leafIndex, Cnt& c)
 {
     const V3 ls = lr.s, ld = lr.d;
     if (N.geomKind == 0) {   // Plane::intersect, geometry.cpp:30-50
@@ -627,17 +662,19 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, L
         ipl = h.ip;
         tri = h.code;
         t = h.dist;
+        leafKind = 2; leafIndex = N.geomIndex;
         return true;
     }
     if ((ST & 2) && N.geomKind == 4) {   // CSG: the winner is re-derived in finalize_hit
         GHit h;
         bool env = false;
-        if (!csg_intersect<ST, FRAY_CSG_DEPTH - 1>(S, S.csgs[N.geomIndex], ls, ld, ray_rdir(ld), h, env, c)) return false;
+        if (!csg_intersect<ST>(S, N.geomIndex, ls, ld, ray_rdir(ld), h, env, c)) return false;
         if (env) c.envelope = 1;
         ipl = h.ip;
         tri = h.code;
         t = h.dist;
         l2 = h.l2; l3 = h.l3;
+        leafKind = h.leafKind; leafIndex = h.leafIndex;
         return true;
     }
     // mesh
@@ -680,7 +717,7 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, L
 
 // Node::intersect (geometry.cpp:196-208) reduced to what the closest-hit comparison needs.
 template <int ST>
-FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double& dist, double& t, int& tri, double& l2, double& l3, Cnt& c)
+FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double& dist, double& t, int& tri, double& l2, double& l3, V3& ipl, int& leafKind, int& leafIndex, Cnt& c)
 {
     bump<ST>(c.node);
     const FRAY_RO DNode& N = S.nodes[i];
@@ -691,8 +728,7 @@ FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double&
         lr.haveRd = false;
     }
     STAMP(1);
-    V3 ipl;
-    const bool hit = geom_intersect<ST>(S, N, i, lr, ipl, t, tri, l2, l3, c);
+    const bool hit = geom_intersect<ST>(S, N, i, lr, ipl, t, tri, l2, l3, leafKind, leafIndex, c);
     STAMP(5);             // whatever geom_intersect did not stamp itself: planes, spheres, the KD walk
     if (!hit) return false;
     V3 ipw = mulM(ipl, N.T.m) + ld3(N.T.off);
@@ -736,9 +772,11 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitRec& best, Cnt& c)
     lr.haveRd = false;
     for (int i = 0; i < nn; i++) {
         double dist, t, l2 = 0, l3 = 0;
-        int tri = -1;
-        if (node_intersect<ST>(S, i, o, d, lr, dist, t, tri, l2, l3, c) && dist < best.dist) {
+        int tri = -1, leafKind = 0, leafIndex = 0;
+        V3 ipl;
+        if (node_intersect<ST>(S, i, o, d, lr, dist, t, tri, l2, l3, ipl, leafKind, leafIndex, c) && dist < best.dist) {
             best.node = i; best.tri = tri; best.dist = dist; best.t = t; best.l2 = l2; best.l3 = l3;
+            if constexpr ((ST & 2) != 0) { best.ipl = ipl; best.leafKind = leafKind; best.leafIndex = leafIndex; }
         }
     }
     if ((ST & 1) && best.node >= 0) {   // byte model: the winner's corner normals / uvs
@@ -774,8 +812,9 @@ FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c)
     lr.haveRd = false;
     for (int i = 0; i < nn; i++) {
         double dist, t, l2, l3;
-        int tri;
-        if (node_intersect<ST>(S, i, a, d, lr, dist, t, tri, l2, l3, c) && dist < maxDist) return false;
+        int tri, leafKind, leafIndex;
+        V3 ipl;
+        if (node_intersect<ST>(S, i, a, d, lr, dist, t, tri, l2, l3, ipl, leafKind, leafIndex, c) && dist < maxDist) return false;
     }
     return true;
 }

@@ -33,7 +33,9 @@
 #define FRAY_WHITTED_REFILL 64  // idle lanes of a wave before they are handed new pixels (k_whitted); measured on dragon / smallpt Whitted: 1 -> 28.9 / 3.53 ms
 #endif
 #ifndef FRAY_CSG_WAVES
-#define FRAY_CSG_WAVES 8        // the Cube / CSG kernel variants (flag bit 1): the hit lists' sorting code wants registers more than the chip wants waves
+#define FRAY_CSG_WAVES 3        // the Cube / CSG kernel variants (flag bit 1): the CsgOp machine's state on top of the KD walk wants registers more than the chip wants waves --
+                                // tests/scenes/csg_nested.fray 960x720 path traced: 111 ms at 4 waves/SIMD (k_pt_bounce<2> 128 VGPR, 203 spilled), 80 ms at 3 (168, 129), 89 ms at 2 (227, none);
+                                // bokeh.fray (k_whitted<2>, at 3 either way) 66.3 / 67.5 / 69.9 ms (profiles/r04_experiments/README.md D)
 #endif
 // waves per SIMD a kernel is register-allocated for: `n` for the common variants, FRAY_CSG_WAVES for the Cube / CSG ones
 constexpr int waves_for(int st, int n) { return (st & 2) ? (FRAY_CSG_WAVES < n ? FRAY_CSG_WAVES : n) : n; }

@@ -104,6 +104,7 @@ class TileGather:
         self.stage_host = stage_host      # transport cannot move device memory (gloo rehearsal): bounce through the host
         n = bucket_count(W, H, 0, world) * BUCKET * BUCKET * channels        # rank 0 owns the most buckets
         self.packed = torch.zeros(n, dtype=torch.float32, device=device)
+        # the root's receive side: one block per rank, each the size of ONE rank's share (1 / world of the frame), i.e. one frame in total
         self.recv = [torch.zeros_like(self.packed) for _ in range(world)] if rank == dst else None
 
     def gather(self, frame):

@@ -19,7 +19,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")      # GOLDEN_OUT: tests/test_oracle_vs_ref_fuzz.py makes throw-away fixtures
 
 CASES = [
     # name, scene, W, H, overrides, probe stride, n random rays
@@ -43,6 +43,30 @@ CASES = [
     ("forest_env_dof", "forest.fray", 48, 30, "wantAA=0;dof=1;numDOFSamples=6", 5, 0),
 ]
 ENV_LOADED = {"forest_env_whitted", "forest_env_dof"}
+# Scenes nobody hand-picked: tests/test_fuzz_parity.py's generator (bump maps on meshes only: on a Sphere / Cube the reference reads uninitialised
+# memory), written once to tests/scenes/fuzz<seed>/ and rendered with the integrator seed % 2 selects.  tests/test_oracle_vs_ref_fuzz.py runs
+# 50 more of them through oracle/_ref and the oracle without keeping them.
+FUZZ_SEEDS = [3001, 3002, 3003, 3004, 3006, 3009, 3010, 3014]
+
+
+def fuzz_cases():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("FRAYHIP_NO_TORCH", "1")
+    import pathlib
+    from test_fuzz_parity import random_scene
+    import fray_amd
+    out = []
+    for seed in FUZZ_SEEDS:
+        folder = pathlib.Path(ROOT) / "tests" / "scenes" / ("fuzz%d" % seed)
+        folder.mkdir(parents=True, exist_ok=True)
+        gi = seed % 2
+        random_scene(np.random.default_rng(seed), folder, gi, flavour=seed % 3, bump_on=("blob",))
+        s = fray_amd.Scene.parseScene(str(folder / "scene.fray"))
+        W, H = s.settings.frameWidth, s.settings.frameHeight
+        s.close()
+        out.append(("fuzz%d_%s" % (seed, "pt" if gi else "whitted"), "../tests/scenes/fuzz%d/scene.fray" % seed, W, H, "gi=%d" % gi, 2, 300))
+    return out
 
 
 def dump_faces(scene, folder):
@@ -112,7 +136,7 @@ if __name__ == "__main__":
     else:
         os.makedirs(OUT, exist_ok=True)
         only = os.environ.get("GOLDEN_ONLY", "").split(",") if os.environ.get("GOLDEN_ONLY") else None
-        for c in CASES:
+        for c in CASES + fuzz_cases():
             if only and c[0] not in only:
                 continue
             env = dict(os.environ)

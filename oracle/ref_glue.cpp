@@ -267,14 +267,17 @@ static Color pathtraceRef(Ray ray, Color weight)
         Color c0;
         float p0;
         sh->spawnRay(h.info, ray, thrown, c0, p0);                 // discarded draw
-        direct.push_back(sampleOneLight(ray, h.info, weight, sh));
+        const Color contribLight = sampleOneLight(ray, h.info, weight, sh);   // evaluated (it draws random numbers) before the real spawn, main.cpp:227-228
         Ray next = ray;
         next.depth++;
         Color f;
         float pdf;
         sh->spawnRay(h.info, ray, next, f, pdf);
+        // main.cpp:238-239: both sentinels return WITHOUT this bounce's light term (unreachable with the shaders fray ships: their spawnRay
+        // yields 1 / 2pi, 1e9 or 1 -- shading.cpp:98,225,294,297, shading.h:133 -- but the restatement must not be the sloppier of the two)
         if (pdf == -1) { tail = Color(1, 0, 0); break; }
         if (pdf == 0) break;
+        direct.push_back(contribLight);
         weight = weight * f / pdf;
         ray = next;
     }
@@ -376,8 +379,22 @@ void ref_render(float* rgb, unsigned seed)
                 if (jitter) { ox = g_local.randfloat(); oy = g_local.randfloat(); }
                 else { ox = (float)aa[i][0]; oy = (float)aa[i][1]; }
                 double fx = x + ox, fy = y + oy;
-                Ray ray = scene.camera->dof ? scene.camera->getDOFRay(fx, fy) : scene.camera->getScreenRay(fx, fy);
-                sum += scene.settings.gi ? pathtraceRef(ray, Color(1, 1, 1)) : raytrace(ray);
+                // raytraceSinglePixel / getRay / trace, main.cpp:287-321 (restated): both eyes' rays are made before either is traced
+                auto getRay = [&](WhichCamera which) { return scene.camera->dof ? scene.camera->getDOFRay(fx, fy, which) : scene.camera->getScreenRay(fx, fy, which); };
+                auto trace = [&](const Ray& r) { return scene.settings.gi ? pathtraceRef(r, Color(1, 1, 1)) : raytrace(r); };
+                if (scene.camera->stereoSeparation > 0) {
+                    Ray leftRay = getRay(CAMERA_LEFT);
+                    Ray rightRay = getRay(CAMERA_RIGHT);
+                    Color colorLeft = trace(leftRay);
+                    Color colorRight = trace(rightRay);
+                    if (scene.settings.saturation != 1) {
+                        colorLeft.adjustSaturation(scene.settings.saturation);
+                        colorRight.adjustSaturation(scene.settings.saturation);
+                    }
+                    sum += colorLeft * scene.camera->leftMask + colorRight * scene.camera->rightMask;
+                } else {
+                    sum += trace(getRay(CAMERA_CENTER));
+                }
             }
             sum = sum / spp;
             float* o = rgb + 3 * (y * g_w + x);

@@ -168,15 +168,23 @@ def test_bucket_numbering_is_the_documented_one(fray):
 
 
 def test_build_recipe_keeps_what_correctness_depends_on(fray):
-    """Two build facts the pictures depend on (both found the hard way): the Cube / CSG kernel variants are compiled with their SGPR
-    spills in scratch memory (with lane spills two equivalent source changes made k_whitted<2> / k_pt_shadow<2> render wrong pictures), and the host
-    code takes sine and cosine of an angle from ONE sincos() call like the reference's g++ build (clang would call sin() and cos(), whose sine
-    differs in the last place for one angle in 700).  The library must therefore import sincos and neither sin nor cos."""
+    """Build facts the pictures depend on.  (1) Round 3 compiled the Cube / CSG kernel variants with -amdgpu-spill-sgpr-to-vgpr=false
+    because, with SGPR spills in VGPR lanes, two equivalent source changes made k_whitted<2> / k_pt_shadow<2> render wrong pictures; those variants
+    were the only ones with out-of-line calls (sixteen CsgOp levels).  Round 4 rebuilt CsgOp::intersect as one loop over an explicit stack: NO device
+    function is called anywhere any more, the flag is gone, and both facts are checked here -- a call creeping back in must be a decision.  (2) The
+    host code takes sine and cosine of an angle from ONE sincos() call like the reference's g++ build (clang would call sin() and cos(), whose sine
+    differs in the last place for one angle in 700): the library must import sincos and neither sin nor cos."""
+    import glob
+    import re
     mk = open(os.path.join(ROOT, "Makefile")).read()
-    for v in ("VARIANT_FLAGS_2", "VARIANT_FLAGS_3"):
-        line = [l for l in mk.splitlines() if l.startswith(v)]
-        assert line and "-amdgpu-spill-sgpr-to-vgpr=false" in line[0], v
-    assert "$(VARIANT_FLAGS_$*)" in mk
+    assert "spill-sgpr-to-vgpr" not in mk
+    reports = sorted(glob.glob(os.path.join(ROOT, "fray_amd", "csrc", "variant*.resources.txt")))
+    assert len(reports) == 8, reports
+    for r in reports:
+        names = re.findall(r"Function Name: (\S+)", open(r).read())
+        assert names, r
+        for n in names:
+            assert re.match(r"_ZL\d+k_", n), (os.path.basename(r), n, "is not a kernel: an out-of-line device function")
     import subprocess
     so = os.path.join(ROOT, "fray_amd", "libfrayhip.so")
     syms = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout

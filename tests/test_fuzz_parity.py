@@ -59,9 +59,12 @@ def write_bmp(path, rgb):
         f.write(data)
 
 
-def random_scene(rng, tmp, gi, flavour=0):
+def random_scene(rng, tmp, gi, flavour=0, bump_on=("ball", "blob", "box")):
     """flavour 0: every geometry kind (the Cube / CSG kernel variants); 1: no Cube / CSG (the KD variants); 2: no Cube / CSG and no mesh big
-    enough for a KD-tree (the lean variants, with textures)"""
+    enough for a KD-tree (the lean variants, with textures).
+    bump_on: the geometries that may get a bump map.  Only Mesh::intersectTriangle writes info.dNdx / dNdy (mesh.cpp:135-136); a bump map on a Sphere
+    or a Cube makes the reference read an uninitialised IntersectionInfo (geometry.h:33-39, Vector() {} -- shading.cpp:416), so comparisons with the
+    reference's object code (tests/test_oracle_vs_ref_fuzz.py) pass ("blob",); the product and the oracle define those vectors as zero."""
     W, H = int(rng.integers(40, 90)), int(rng.integers(30, 70))
     s = ["GlobalSettings {\n\tframeWidth %d\n\tframeHeight %d\n\tambientLight (0.15, 0.15, 0.2)\n\tmaxTraceDepth %d\n\twantAA %s\n\tgi %d\n\tpathsPerPixel %d\n}" %
          (W, H, int(rng.integers(2, 5)), "on" if (not gi and rng.random() < 0.3) else "off", gi, int(rng.choice([3, 9])))]   # 9 spp: four batches on four streams
@@ -109,7 +112,7 @@ def random_scene(rng, tmp, gi, flavour=0):
     for i, g in enumerate(geoms):
         sh = shaders[int(rng.integers(len(shaders)))]
         sc = 0.6 + rng.random() * 1.2
-        bump = "\n\tbump dents" if (g in ("ball", "blob", "box") and rng.random() < 0.4) else ""
+        bump = "\n\tbump dents" if (g in ("ball", "blob", "box") and rng.random() < 0.4 and g in bump_on) else ""
         s.append("Node n%d {\n\tgeometry %s\n\tshader %s%s\n\tscale (%.3f, %.3f, %.3f)\n\trotate (%.1f, %.1f, %.1f)\n\ttranslate (%.2f, %.2f, %.2f)\n}" %
                  (i, g, sh, bump, sc, sc * (0.7 + rng.random() * 0.6), sc, rng.random() * 360, rng.normal() * 20, rng.normal() * 20,
                   (i - 3.5) * 2.4 + rng.normal() * 0.3, rng.random() * 2, rng.normal() * 1.5))

@@ -38,6 +38,64 @@ def test_bench_two_ranks_gather_equals_single_rank_frame(tmp_path, workload):
     assert r["value"] > 0 and r["scaling"] == "strong"
 
 
+def test_bench_gpus_2_typed_like_the_single_gpu_command_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` WITHOUT a launcher (the command the driver uses for N = 1, with another N): bench.py starts the ranks itself, as
+    children of a launcher that is its own child, and relays rank 0's ONE JSON line."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo", "--check", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = run_in_clean_child(cmd, str(tmp_path / "bench.log"), timeout=600, env=env)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-3000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["gathered_frame_equals_single_rank_frame"] is True and "[exit code 0]" in out, out[-2000:]
+    assert "starting 2 ranks" in out and "torch.distributed.run" in out
+    assert r["config"]["ranks_seen_by_rccl"] is None            # a gloo rehearsal on one GPU: the exchange did not run on RCCL, and the line says so
+
+
+def test_comm_from_nccl_wraps_a_communicator_the_host_owns(fray, gpu):
+    """frayhip_comm_from_nccl: a world-of-one ncclComm_t made by the host itself (RCCL through ctypes: the copy PyTorch already mapped) is accepted, reports
+    ONE rank seen by RCCL, gathers in place; a world / rank that is not the communicator's own is refused; destroying the wrapper leaves the host's
+    communicator alive."""
+    import torch
+    lib = fray.lib
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+        try:
+            rccl = C.CDLL(name, mode=os.RTLD_NOLOAD | os.RTLD_NOW | os.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        rccl = C.CDLL("librccl.so.1")
+    torch.zeros(1, device="cuda")                                # the device is current and initialised
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    nc = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(nc), 1, uid, 0) == 0 and nc.value
+    comm = C.c_void_p()
+    assert lib.frayhip_comm_from_nccl(nc, 0, 1, C.byref(comm)) == 0, lib.frayhip_last_error()
+    assert lib.frayhip_comm_ranks(comm) == 1
+    frame = torch.rand((100, 150, 3), device="cuda")
+    before = frame.clone()
+    assert lib.frayhip_gather_buckets(comm, frame.data_ptr(), 150, 100, 3, 0, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(frame, before)
+    lib.frayhip_comm_destroy(comm)
+    bad = C.c_void_p()
+    assert lib.frayhip_comm_from_nccl(nc, 0, 2, C.byref(bad)) != 0 and b"communicator says" in lib.frayhip_last_error()
+    assert lib.frayhip_comm_from_nccl(None, 0, 1, C.byref(bad)) != 0
+    # the host's communicator survived the wrapper
+    n = C.c_int(0)
+    rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    assert rccl.ncclCommCount(nc, C.byref(n)) == 0 and n.value == 1
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    assert rccl.ncclCommDestroy(nc) == 0
+
+
 def test_library_gather_single_rank_and_argument_checks(fray, gpu):
     """frayhip_comm_* / frayhip_gather_buckets as far as one rank goes: the id comes from RCCL itself, a world of one
     gathers in place, bad arguments are refused."""
@@ -52,6 +110,7 @@ def test_library_gather_single_rank_and_argument_checks(fray, gpu):
     assert lib.frayhip_gather_buckets(comm, frame.data_ptr(), 200, 130, 3, 0, None) == 0
     torch.cuda.synchronize()
     assert torch.equal(frame, before)
+    assert lib.frayhip_comm_ranks(comm) == 1
     assert lib.frayhip_gather_buckets(comm, frame.data_ptr(), 200, 130, 3, 1, None) != 0      # root outside the world
     assert lib.frayhip_gather_buckets(comm, None, 200, 130, 3, 0, None) != 0
     lib.frayhip_comm_destroy(comm)

@@ -408,3 +408,40 @@ def test_certified_triangle_filter_never_rejects_what_the_reference_accepts(tmp_
     assert int(r.stdout.split("reference accepts")[1].split()[0]) > 500000, r.stdout     # ... and aim at triangles
     r = subprocess.run([exe, "1500000", "1e-7"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "mismatches 0" not in r.stdout, r.stdout
+
+
+# ---- the product's parser against the reference's parser OBJECT CODE (tests/golden/ref_parse.json, made by oracle/make_parse_golden.py from oracle/_ref:
+# ---- scene.o with every fillProperties, the OBJ / BMP loaders, Transform) -- not against this project's reading of the grammar
+def _ref_parse_golden():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_parse.json")))
+
+
+def _compare_with_reference_dump(fray, path, ref_lines):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle import scene_dump
+    if ref_lines is None:
+        with pytest.raises(fray.FrayError):        # the reference rejects this text: so must the product
+            fray.Scene.parseScene(path)
+        return
+    s = fray.Scene.parseScene(path)
+    diff = scene_dump.first_difference(scene_dump.dump(s.desc), [l.split() for l in ref_lines])
+    s.close()
+    assert diff is None, "line %d, token %d: product %s, reference %s" % diff
+
+
+@pytest.mark.parametrize("name", sorted(_ref_parse_golden()["cases"]))
+def test_parser_edge_cases_equal_the_reference_parsers_scene(fray, tmp_path, name):
+    """Comments, quotes, singleton blocks, the one-line block the grammar rejects, transform lines in file order (nodes and a RectLight), Layered lines with
+    forward references, randfloat / randint macros (drawn from the generator initRandom(42) leaves in table entry 0), CsgOp trees with every texture and
+    shader kind, OBJ fans with missing / negative / zero indices, every camera and settings field: settings, camera, lights and every
+    render-list node's transform (27 doubles), geometry tree and shader tree must equal what the reference's scene.o made of the same text."""
+    from parser_cases import write_case
+    _compare_with_reference_dump(fray, write_case(name, str(tmp_path)), _ref_parse_golden()["cases"][name])
+
+
+@pytest.mark.parametrize("name", sorted(_ref_parse_golden()["scenes"]))
+def test_repository_scene_files_parse_like_the_reference(fray, name):
+    from conftest import SCENES
+    _compare_with_reference_dump(fray, os.path.join(SCENES, name), _ref_parse_golden()["scenes"][name])

@@ -232,10 +232,10 @@ def test_shipped_scenes_parse(fray):
 
 
 def test_exr_piz_cubemap_decodes(fray, oracle):
-    """forest.fray's environment: six 256x256 half-RGBA PIZ faces.  The Huffman stage checks itself
-    (exact bit and symbol counts); the image statistics catch a wrong wavelet / LUT stage; the
-    hashes are regression values produced by this decoder (no OpenEXR library exists here to
-    cross-check against)."""
+    """forest.fray's environment: six 256x256 half-RGBA PIZ faces.  The Huffman stage checks itself (exact bit and symbol counts); the image
+    statistics catch a wrong wavelet / LUT stage; the hashes were produced by oracle/exr_piz_reader.py, an INDEPENDENT reader written from the OpenEXR
+    file-layout / PIZ description (oracle/make_exr_hashes.py) -- the reference decodes through the OpenEXR library, which this image lacks, so two
+    implementations sharing only the specification are the strongest pin there is; see also the two tests below."""
     s = open_scene(fray, "forest.fray")
     e = s.desc.environment
     assert e.present == 1 and e.loaded == 1
@@ -247,7 +247,7 @@ def test_exr_piz_cubemap_decodes(fray, oracle):
         # natural image: neighbouring rows are strongly correlated, and far smoother than shuffled data
         assert np.corrcoef(img[100, :, 1], img[101, :, 1])[0, 1] > 0.7
         assert np.abs(np.diff(img, axis=0)).mean() < 0.5 * np.abs(img - np.roll(img, 97, axis=0)).mean()
-    # regression pins of the decoded texels (oracle/make_exr_hashes.py): a decoder change that moves a single bit of a face fails here
+    # the independent reader's hashes of the decoded texels (oracle/make_exr_hashes.py): a single differing bit of a face fails here
     import json
     pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "exr_face_hashes.json")))["forest.fray"]
     for f in range(6):
@@ -445,3 +445,65 @@ def test_parser_edge_cases_equal_the_reference_parsers_scene(fray, tmp_path, nam
 def test_repository_scene_files_parse_like_the_reference(fray, name):
     from conftest import SCENES
     _compare_with_reference_dump(fray, os.path.join(SCENES, name), _ref_parse_golden()["scenes"][name])
+
+
+def test_exr_decoder_equals_the_independent_reader_texel_for_texel(fray):
+    """fray_amd/csrc/host_exr.cpp against oracle/exr_piz_reader.py on the six shipped cubemap faces: the same float32 RGB arrays, bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from conftest import SCENES
+    from oracle import exr_piz_reader
+    s = open_scene(fray, "forest.fray")
+    e = s.desc.environment
+    tex = np.ctypeslib.as_array(s.desc.texels, shape=(s.desc.n_texels,))
+    for f, name in enumerate(("negx", "negy", "negz", "posx", "posy", "posz")):
+        mine = tex[e.texel_offset[f]:e.texel_offset[f] + e.width[f] * e.height[f] * 3].reshape(e.height[f], e.width[f], 3)
+        theirs = exr_piz_reader.read_rgb(os.path.join(SCENES, "env", "forest", name + ".exr"))
+        assert theirs.shape == mine.shape and np.array_equal(mine, theirs), name
+    s.close()
+
+
+@pytest.mark.parametrize("kind,h,w", [("smooth", 64, 64), ("smooth", 37, 21), ("smooth", 33, 70), ("few", 45, 45), ("few", 5, 3), ("few", 1, 1), ("noise", 40, 17),
+                                      ("const", 70, 9), ("smooth", 1, 50), ("smooth", 50, 1), ("few", 96, 31)])
+def test_exr_piz_files_of_other_shapes_decode_to_what_was_written(fray, tmp_path, kind, h, w):
+    """The shipped faces are 256 x 256 with wide value ranges: they never take the wavelet's 1-D steps for odd rows / columns, its 14-bit form (fewer
+    than 2^14 distinct values), the Huffman run-length code, or blocks stored raw.  oracle/exr_piz_writer.py makes PIZ files that do (odd sizes down to
+    1 x 1, eight distinct values, constant areas, incompressible noise), and BOTH decoders -- the product's and the independent reader -- must return
+    exactly the half-float values that were written."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle import exr_piz_reader, exr_piz_writer
+    rng = np.random.default_rng(h * 1000 + w)
+
+    def make():
+        if kind == "smooth":
+            y, x = np.mgrid[0:h, 0:w]
+            base = np.sin(x * 0.2) * np.cos(y * 0.13) + 1.5 + rng.normal(size=(h, w)) * 0.05
+            return {c: (base * (i + 1)).astype(np.float32) for i, c in enumerate("RGBA")}
+        if kind == "few":
+            vals = np.array([0, 0.25, 0.5, 1, 2, 4, 8.5, 100], np.float32)
+            img = {c: vals[rng.integers(0, len(vals), size=(h, w))] for c in "RGB"}
+            img["R"][:h // 2] = 0.5
+            return img
+        if kind == "noise":
+            return {c: rng.random((h, w)).astype(np.float32) * 1000 for c in "RGBA"}
+        return {c: np.full((h, w), 3.0, np.float32) for c in "RGB"}
+
+    (tmp_path / "env").mkdir()
+    written = {}
+    for face in ("negx", "negy", "negz", "posx", "posy", "posz"):
+        written[face] = exr_piz_writer.write_exr(str(tmp_path / "env" / (face + ".exr")), make())
+        _, _, got = exr_piz_reader.read_exr(str(tmp_path / "env" / (face + ".exr")))
+        for c, v in written[face].items():
+            assert np.array_equal(got[c], v), (face, c)
+    (tmp_path / "scene.fray").write_text('Camera camera {\n\tposition (0,0,0)\n}\nCubemapEnvironment environment {\n\tfolder "env"\n}\n')
+    s = fray.Scene.parseScene(str(tmp_path / "scene.fray"))
+    e = s.desc.environment
+    assert e.present == 1 and e.loaded == 1
+    tex = np.ctypeslib.as_array(s.desc.texels, shape=(s.desc.n_texels,))
+    for f, face in enumerate(("negx", "negy", "negz", "posx", "posy", "posz")):
+        assert (e.width[f], e.height[f]) == (w, h)
+        mine = tex[e.texel_offset[f]:e.texel_offset[f] + w * h * 3].reshape(h, w, 3)
+        want = np.stack([written[face].get(c, np.zeros((h, w), np.float32)) for c in "RGB"], axis=2)
+        assert np.array_equal(mine, want), face
+    s.close()

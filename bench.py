@@ -357,22 +357,41 @@ def main():
     # pass of the same frames (one batch lane: every launch alone on the chip, HIP events around each launch on the
     # stream it runs on) -- the same mode the kept rocprofv3 kernel trace under profiles/ is collected in.
     serial = None
+    serial_note = None
     if rank == 0 and world == 1 and scene.settings.gi and not args.no_serial_pass:
         lanes_before = int(os.environ.get("FRAYHIP_PT_LANES", "4") or 4)       # the library's own default (render_state.hpp) unless the environment presets it
-        scene.set_option("pt_lanes", 1)
-        step()
+        # A frame that takes seconds (4096 x 4096 x 1024 spp: 13 s) is not rendered twice more: its serialised pass renders the SAME frame with fewer
+        # samples per pixel -- the batches, hence the launches, keep their size (a batch's samples per pixel follow from the queue budget and the frame's
+        # pixels, not from spp), there are just fewer of them.  Launch counts are then scaled back to the full frame.
+        spp_full = scene.samples_per_pixel()
+        spp_ser = spp_full
+        if ms_per_step > 1500.0 and spp_full > 32:
+            spp_ser = 32
+        ser_scene = scene
+        if spp_ser != spp_full:
+            ser_scene = open_scene(fray_amd, name, W, H, dict(over, numPaths=spp_ser))
+            ser_scene.beginRender()
+            serial_note = "a frame of %d spp instead of %d (same batches, fewer of them); launch counts scaled by %g" % (spp_ser, spp_full, spp_full / spp_ser)
+
+        def ser_step():
+            return ser_scene.render_device(frame.data_ptr(), seed=args.seed, bucket_first=0, bucket_stride=1, spp_chunk=args.spp_chunk, stream=stream_ptr(), mode=mode)
+        ser_scene.set_option("pt_lanes", 1)
+        ser_step()
         torch.cuda.synchronize()
         n_ser = max(1, min(args.steps, 3))
         t1 = time.perf_counter()
         acc = {"ms_trace": 0.0, "trace_launches": 0, "ms_shadow": 0.0, "shadow_launches": 0, "ms_kernels": 0.0}
         for _ in range(n_ser):
-            st = step()
+            st = ser_step()
             for k in acc:
                 acc[k] += st[k]
         torch.cuda.synchronize()
-        serial = {k: v / n_ser for k, v in acc.items()}
-        serial["ms_per_step"] = (time.perf_counter() - t1) * 1e3 / n_ser
-        scene.set_option("pt_lanes", lanes_before)
+        scale = spp_full / spp_ser
+        serial = {k: v / n_ser * scale for k, v in acc.items()}
+        serial["ms_per_step"] = (time.perf_counter() - t1) * 1e3 / n_ser * scale
+        ser_scene.set_option("pt_lanes", lanes_before)
+        if ser_scene is not scene:
+            ser_scene.close()
 
     if rank == 0:
         from tools.source_hash import source_hash
@@ -412,7 +431,7 @@ def main():
             "roofline": {"bound": "fp64_valu", "kernel": kern, "achieved": tf, "peak": FP64_PEAK, "unit": "TFLOP/s", "frac": tf / FP64_PEAK,
                          "alg_flops_per_launch": flops_per_launch, "avg_launch_ms": avg_launch_ms, "launches_per_step": tr_n,
                          "sum_launch_ms_per_step": tr_ms,
-                         "durations_from": ("serialised pass (pt_lanes = 1), %.2f ms per frame" % serial["ms_per_step"]) if serial else "the timed region",
+                         "durations_from": ("serialised pass (pt_lanes = 1), %.2f ms per frame%s" % (serial["ms_per_step"], (": " + serial_note) if serial_note else "")) if serial else "the timed region",
                          "traffic": None, "counters": None, "source_hash": src},
             # The contract's HBM figure: SURVEY 8(d) algorithmic bytes over the same durations.  Those bytes are node transforms and
             # triangle records served by the scalar cache / L2 (the scene is a few KB), so this is NOT a DRAM rate and may exceed the peak.
@@ -465,6 +484,14 @@ def main():
                             out[key]["traffic_note"] = k.get("hbm_note")
                             out[key]["counters"] = k.get("derived")
                             out[key]["profile_avg_launch_ms"] = k.get("avg_launch_ms")
+                            mix = k.get("instruction_mix_per_launch")
+                            if mix:
+                                # MEASURED beside the estimate: FP64 wave-instructions the kernel issued per launch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64), as lane
+                                # operations at the measured lane utilisation, next to alg_flops_per_launch (SURVEY 8d operation counts x work counters)
+                                lanes = (k.get("derived") or {}).get("lane_utilisation") or 1.0
+                                out[key]["fp64_wave_instructions_measured"] = mix["fp64_wave_instructions"]
+                                out[key]["fp64_ops_measured"] = mix["fp64_wave_instructions"] * 64.0 * lanes
+                                out[key]["instruction_mix"] = {a: b for a, b in mix.items() if a != "fp64_wave_instructions"}
                 else:
                     out["roofline"]["counters_note"] = "%s is for source %s / %s: not this build" % (os.path.relpath(pmc_path, ROOT), pmc.get("source_hash"), pmc.get("workload"))
             except (KeyError, ValueError, OSError):

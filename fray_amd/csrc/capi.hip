@@ -145,15 +145,32 @@ int ensure_work(frayhip_scene* sc, size_t bytes)
     return FRAYHIP_OK;
 }
 
-// The queue budget a frame may plan with: the tunable (pt_budget_mib), but never more than four fifths of what the device can still give
-// (free memory plus the workspace this scene already holds) -- on a smaller or busy GPU, or with several ranks sharing one for a
-// rehearsal, the frame is then cut into smaller batches instead of failing with E_NOMEM.
-size_t work_budget(const frayhip_scene* sc)
+// The queue budget a frame may plan with: the tunable (pt_budget_mib), but never more than four fifths of what the device could give when the
+// clamp was taken (free memory plus the workspace this scene already holds) -- on a smaller or busy GPU, or with several ranks sharing one for a
+// rehearsal, the frame is then cut into smaller batches instead of failing with E_NOMEM.  The clamp is taken ONCE (first use after scene creation
+// or after a change of the option): asking hipMemGetInfo every frame made the batch size follow other processes' allocations, and every growth of
+// the workspace is a hipFree + hipMalloc in the middle of a run.  Ranks that share a GPU all see the same free memory at the same moment and may
+// each plan with four fifths of it: an allocation that fails all the same halves the budget and the frame is planned again (ensure_work_or_shrink).
+size_t work_budget(frayhip_scene* sc)
 {
-    size_t freeB = 0, totalB = 0;
-    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return sc->ptBudgetBytes;
-    const size_t avail = (freeB + sc->work_bytes) / 5 * 4;
-    return std::max<size_t>(std::min(sc->ptBudgetBytes, avail), (size_t)64 << 20);
+    if (!sc->ptBudgetEff) {
+        size_t freeB = 0, totalB = 0;
+        size_t b = sc->ptBudgetBytes;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) b = std::min(b, (freeB + sc->work_bytes) / 5 * 4);
+        sc->ptBudgetEff = std::max<size_t>(b, (size_t)64 << 20);
+    }
+    return sc->ptBudgetEff;
+}
+
+// ensure_work for a plan made under work_budget(): FRAYHIP_OK, an error, or FRAYHIP_RETRY_SMALLER after halving the budget (the caller plans again).
+int ensure_work_or_shrink(frayhip_scene* sc, size_t bytes)
+{
+    const int rc = ensure_work(sc, bytes);
+    if (rc != FRAYHIP_E_NOMEM) return rc;
+    (void)hipGetLastError();
+    if (work_budget(sc) <= ((size_t)64 << 20)) return rc;          // already at the floor: give up with the allocation's message
+    sc->ptBudgetEff = std::max<size_t>(sc->ptBudgetEff / 2, (size_t)64 << 20);
+    return FRAYHIP_RETRY_SMALLER;
 }
 
 hipEvent_t pool_event(std::vector<hipEvent_t>& pool, size_t i)
@@ -610,7 +627,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     }
     // profiling aids: the same knobs as frayhip_scene_set_option, preset from the environment
     if (const char* e = getenv("FRAYHIP_PT_LANES")) { long v = atol(e); if (v >= 1 && v <= FRAY_PT_LANES) sc->ptLanes = (int)v; }
-    if (const char* e = getenv("FRAYHIP_PT_BUDGET_MIB")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) sc->ptBudgetBytes = (size_t)v << 20; }
+    if (const char* e = getenv("FRAYHIP_PT_BUDGET_MIB")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) { sc->ptBudgetBytes = (size_t)v << 20; sc->ptBudgetEff = 0; } }
     *out = sc;
     return FRAYHIP_OK;
 }
@@ -625,6 +642,7 @@ int frayhip_scene_set_option(frayhip_scene* s, const char* name, int64_t value)
     } else if (n == "pt_budget_mib") {
         if (value < 1 || value > (1 << 20)) { set_error("frayhip_scene_set_option: pt_budget_mib must be 1..1048576"); return FRAYHIP_E_ARG; }
         s->ptBudgetBytes = (size_t)value << 20;
+        s->ptBudgetEff = 0;                 // clamp again at the next frame
     } else {
         set_error("frayhip_scene_set_option: unknown option " + n);
         return FRAYHIP_E_ARG;

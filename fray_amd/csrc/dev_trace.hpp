@@ -20,6 +20,9 @@
 #define FRAY_CERT_SEQ() __builtin_amdgcn_sched_barrier(0)
 #include "dev_boxcert.hpp"
 
+#ifdef FRAY_LEAFSTAT
+static __device__ unsigned long long g_leafStat[4];      // diagnostic build only, read back by render_impl (FRAY_LEAFSTAT)
+#endif
 // Per-lane work counters (frayhip_stats); only the <true> instantiations touch them.
 struct Cnt {
     unsigned long long closest, shadow, node, kdInner, leafRefs, tri, prim, smooth, samples, tex;
@@ -360,10 +363,24 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
         if (!alive) return false;
         // ---- leaf: test every triangle, accept iff found && inside(leaf box, ip)
         {
-            const int beg = kd[leaf].triBegin, cnt = kd[leaf].triCount;
+#ifdef FRAY_LEAFSTAT
+            {   // diagnostic build: how coherent are the lanes of a wave when they reach their leaves?  [0] leaf phases of a wave, [1] phases in which every
+                // active lane stands in the SAME leaf, [2] active lanes summed, [3] distinct leaves summed (counted by peeling off the first lane's leaf)
+                const unsigned long long act = __ballot(true);
+                unsigned long long rest = act;
+                int distinct = 0;
+                while (rest) {
+                    const int l0 = __builtin_amdgcn_readlane(leaf, (int)__builtin_ctzll(rest));
+                    rest &= ~__ballot(leaf == l0);
+                    distinct++;
+                }
+                if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) {
+                    atomicAdd(&g_leafStat[0], 1ull); if (distinct == 1) atomicAdd(&g_leafStat[1], 1ull);
+                    atomicAdd(&g_leafStat[2], (unsigned long long)__popcll(act)); atomicAdd(&g_leafStat[3], (unsigned long long)distinct);
+                }
+            }
+#endif
             bool found = false;
-            const FRAY_RO DTri* lt = M.ltris + beg;
-            const FRAY_RO DTri32* lf = M.ltris32 + beg;
             // the ray as the certified triangle filter reads it (dev_tricert.hpp): FP32, relative to the mesh's reference point.  Made again in
             // every leaf (nine instructions) rather than kept in seven registers through the walk
             // (the empty asm keeps the optimiser from hoisting the conversions out of the walk's loop, where they would hold those registers)
@@ -372,6 +389,9 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
             const float s32x = (float)(hx - M.ref[0]), s32y = (float)(hy - M.ref[1]), s32z = (float)(hz - M.ref[2]);
             const float d32x = (float)hdx, d32y = (float)hdy, d32z = (float)hdz;
             const bool rayOk32 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(s32x), __builtin_fabsf(s32y)), __builtin_fabsf(s32z)) <= 1e9f;
+            const int beg = kd[leaf].triBegin, cnt = kd[leaf].triCount;
+            const FRAY_RO DTri* lt = M.ltris + beg;
+            const FRAY_RO DTri32* lf = M.ltris32 + beg;
             // two passes over (at most 32 at a time of) the leaf's triangles: the certified FP32 filter marks the ones the reference's test may
             // accept (dev_tricert.hpp: the others it surely rejects, and a rejected triangle leaves no trace), then the reference's arithmetic
             // runs on the marked ones in their order.  A wave spends its FP64 tests on max-over-lanes CANDIDATES instead of triangles.

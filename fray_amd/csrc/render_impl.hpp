@@ -123,16 +123,22 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 const size_t colBytes = r256((size_t)grid * 256 * 624 * sizeof(uint32_t));
                 // per (pixel, sample): base 12 + a 24 + hit 1 + radiance 12 per eye, 37 per light sample and eye, 4 for the seed
                 const size_t perSlot = eyes * (49 + (size_t)T * 37) + 4;
-                const size_t wb = work_budget(sc);
-                const size_t budget = wb > colBytes + (64u << 20) ? wb - colBytes : (64u << 20);
-                int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / ((size_t)nItems * perSlot));
-                if (chunk > spp) chunk = spp;
-                while (chunk > 1 && (size_t)nItems * chunk * eyes * (size_t)std::max(T, 1) > ((size_t)1 << 31)) chunk /= 2;
-                const size_t slots = (size_t)nItems * chunk, N = slots * eyes, NT = N * (size_t)T;
-                const size_t bytes = colBytes + r256((size_t)nItems * 12) + r256(N * 12) + 3 * r256(N * 8) + r256(N) + 3 * r256(NT * 8) + 3 * r256(NT * 4) + r256(NT) +
-                                     2 * r256(slots * 12) + r256(slots * 4) + 4096;
-                int rc = ensure_work(sc, bytes);
-                if (rc) return rc;
+                int chunk = 0;
+                size_t slots = 0, N = 0, NT = 0;
+                for (;;) {          // planned again with half the budget when the allocation fails (ensure_work_or_shrink)
+                    const size_t wb = work_budget(sc);
+                    const size_t budget = wb > colBytes + (64u << 20) ? wb - colBytes : (64u << 20);
+                    chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / ((size_t)nItems * perSlot));
+                    if (chunk > spp) chunk = spp;
+                    while (chunk > 1 && (size_t)nItems * chunk * eyes * (size_t)std::max(T, 1) > ((size_t)1 << 31)) chunk /= 2;
+                    slots = (size_t)nItems * chunk; N = slots * eyes; NT = N * (size_t)T;
+                    const size_t bytes = colBytes + r256((size_t)nItems * 12) + r256(N * 12) + 3 * r256(N * 8) + r256(N) + 3 * r256(NT * 8) + 3 * r256(NT * 4) + r256(NT) +
+                                         2 * r256(slots * 12) + r256(slots * 4) + 4096;
+                    const int rc = ensure_work_or_shrink(sc, bytes);
+                    if (rc == FRAYHIP_RETRY_SMALLER && f->spp_chunk <= 0 && chunk > 1) continue;
+                    if (rc) { if (rc == FRAYHIP_RETRY_SMALLER) return FRAYHIP_E_NOMEM; return rc; }
+                    break;
+                }
                 unsigned char* p = (unsigned char*)sc->d_work;
                 auto take = [&](size_t b) { unsigned char* r = p; p += r256(b); return r; };
                 uint32_t* mtWork = (uint32_t*)take(colBytes);
@@ -184,21 +190,27 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             // a small frame (an eighth of 1080p x 64 spp, i.e. one rank's share of an 8-rank run) is cut into fewer, larger batches:
             // measured 15.5 ms on three lanes against 15.9 on four; from a quarter of that frame upwards four lanes win
             if (maxLanes > 3 && (size_t)nItems * (size_t)spp < ((size_t)24 << 20)) maxLanes = 3;
-            const size_t budget = std::max<size_t>(work_budget(sc) / perPath, 1);       // paths in flight over all lanes
-            int chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / maxLanes / (size_t)nItems);
-            if (chunk > spp) chunk = spp;
-            if (f->spp_chunk <= 0 && spp >= 2 * maxLanes && chunk * maxLanes > spp) chunk = (spp + maxLanes - 1) / maxLanes;   // enough batches to fill the lanes
-            while (chunk > 1 && (size_t)nItems * chunk > ((size_t)1 << 30)) chunk /= 2;   // slots are 32-bit
-            const int nBatches = (spp + chunk - 1) / chunk;
-            const int nLanes = std::min(nBatches, maxLanes);
-            const size_t nPaths = (size_t)nItems * chunk;
-            // per-wave segments round their share up to a multiple of 64: one extra wave-load per wave of the grid
-            const size_t nQueue = nPaths + (size_t)grid_for(nPaths) * 4 * 128;
             const bool stereo = sc->camera.stereoSeparation > 0;
-            const size_t laneBytes = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + nPaths * 4 + 4096 + nPaths * termBytes + 512 + (longRng ? nPaths * 2 * 624 * sizeof(uint32_t) + 256 : 0) +
-                                     (stereo ? nPaths * (12 + 6 * 8 + 6 * 4) + 16 * 256 : 0);
-            int rc = ensure_work(sc, (size_t)nLanes * laneBytes + (size_t)nItems * 12 + 4096);
-            if (rc) return rc;
+            int chunk = 0, nBatches = 0, nLanes = 0;
+            size_t nPaths = 0, nQueue = 0, laneBytes = 0;
+            for (;;) {              // planned again with half the budget when the allocation fails (ensure_work_or_shrink)
+                const size_t budget = std::max<size_t>(work_budget(sc) / perPath, 1);       // paths in flight over all lanes
+                chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / maxLanes / (size_t)nItems);
+                if (chunk > spp) chunk = spp;
+                if (f->spp_chunk <= 0 && spp >= 2 * maxLanes && chunk * maxLanes > spp) chunk = (spp + maxLanes - 1) / maxLanes;   // enough batches to fill the lanes
+                while (chunk > 1 && (size_t)nItems * chunk > ((size_t)1 << 30)) chunk /= 2;   // slots are 32-bit
+                nBatches = (spp + chunk - 1) / chunk;
+                nLanes = std::min(nBatches, maxLanes);
+                nPaths = (size_t)nItems * chunk;
+                // per-wave segments round their share up to a multiple of 64: one extra wave-load per wave of the grid
+                nQueue = nPaths + (size_t)grid_for(nPaths) * 4 * 128;
+                laneBytes = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + nPaths * 4 + 4096 + nPaths * termBytes + 512 + (longRng ? nPaths * 2 * 624 * sizeof(uint32_t) + 256 : 0) +
+                            (stereo ? nPaths * (12 + 6 * 8 + 6 * 4) + 16 * 256 : 0);
+                const int rc = ensure_work_or_shrink(sc, (size_t)nLanes * laneBytes + (size_t)nItems * 12 + 4096);
+                if (rc == FRAYHIP_RETRY_SMALLER && f->spp_chunk <= 0 && (chunk > 1 || nLanes > 1)) { if (chunk == 1 && maxLanes > 1) maxLanes--; continue; }
+                if (rc) { if (rc == FRAYHIP_RETRY_SMALLER) return FRAYHIP_E_NOMEM; return rc; }
+                break;
+            }
             struct Lane {
                 hipStream_t stream;
                 PathQueue Q[2];
@@ -303,6 +315,15 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     drain.armed = false;                    // every lane was joined into `stream` above
     DStats dsv[2];
     HIP_TRY(hipMemcpy(dsv, sc->d_stats, sizeof dsv, hipMemcpyDeviceToHost));
+#ifdef FRAY_LEAFSTAT
+    {
+        unsigned long long ls[4] = {0, 0, 0, 0}, zero[4] = {0, 0, 0, 0};
+        (void)hipMemcpyFromSymbol(ls, HIP_SYMBOL(g_leafStat), sizeof ls);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_leafStat), zero, sizeof zero);
+        if (ls[0]) fprintf(stderr, "[leafstat] wave leaf phases %llu, all active lanes in ONE leaf %.1f %%, active lanes per phase %.1f, distinct leaves per phase %.2f\n",
+                           ls[0], 100.0 * (double)ls[1] / (double)ls[0], (double)ls[2] / (double)ls[0], (double)ls[3] / (double)ls[0]);
+    }
+#endif
 #ifdef FRAY_STAMPS
     {
         static const char* names[16] = {"queue lookup + ray load / camera ray", "local ray (transform)", "root box test", "tree-less triangle loop", "KD walk: child tests", "other geometry (plane / sphere / KD leaf accept)",

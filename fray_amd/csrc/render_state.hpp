@@ -64,6 +64,10 @@ struct frayhip_scene {
     // tunables (frayhip_scene_set_option; defaults from FRAYHIP_PT_LANES / FRAYHIP_PT_BUDGET_MIB in the environment)
     int ptLanes = FRAY_PT_LANES;
     size_t ptBudgetBytes = (size_t)FRAY_PT_BUDGET_MIB << 20;
+    // what a frame plans with: ptBudgetBytes clamped to the device's free memory ONCE (scene creation, a change of the option) and halved when an
+    // allocation fails all the same -- never re-derived per frame (other processes' allocations would move the batch size, and every growth of the
+    // workspace is a hipFree + hipMalloc in the middle of a run).  0 = not computed yet.
+    size_t ptBudgetEff = 0;
 };
 
 namespace frayhip_detail {
@@ -74,7 +78,9 @@ constexpr size_t kStatsBytes = kCursorOffset + sizeof(DCursors);
 
 DCamera camera_begin_frame(const frayhip_camera& c, int W, int H);
 int persistent_grid(size_t n, int wavesPerSimd);
-size_t work_budget(const frayhip_scene* sc);
+size_t work_budget(frayhip_scene* sc);
+enum { FRAYHIP_RETRY_SMALLER = 1 };      // internal: ensure_work_or_shrink halved the budget, plan the frame again
+int ensure_work_or_shrink(frayhip_scene* sc, size_t bytes);
 int bounce_grid(size_t n);
 int grid_for(size_t n);
 int ensure_work(frayhip_scene* sc, size_t bytes);

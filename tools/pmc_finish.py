@@ -63,16 +63,31 @@ def main():
             # issue slots: every vector instruction holds its SIMD for 4 cycles (FP64, and a lone wave's 32-bit) or 2 (32-bit beside other waves): between x2 and x4
             d["valu_issue_x4"] = per["SQ_INSTS_VALU"] * 4.0 / simd_cycles
             d["valu_issue_x2"] = per["SQ_INSTS_VALU"] * 2.0 / simd_cycles
-        if "TA_TA_BUSY_sum" in per and per.get("GRBM_GUI_ACTIVE"):
-            d["ta_busy"] = per["TA_TA_BUSY_sum"] / (per["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)        # one texture-address unit per CU
-        if "TCP_TCP_TA_DATA_STALL_CYCLES_sum" in per and per.get("GRBM_GUI_ACTIVE"):
-            d["tcp_ta_data_stall"] = per["TCP_TCP_TA_DATA_STALL_CYCLES_sum"] / (per["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)
-        if "TCP_GATE_EN1_sum" in per and per.get("GRBM_GUI_ACTIVE"):
-            d["tcp_busy"] = per["TCP_GATE_EN1_sum"] / (per["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)
-        if "TCP_TOTAL_ACCESSES_sum" in per and per.get("TA_FLAT_READ_WAVEFRONTS_sum"):
-            d["l1_accesses_per_load_instruction"] = per["TCP_TOTAL_ACCESSES_sum"] / per["TA_FLAT_READ_WAVEFRONTS_sum"]     # cache lines one wave-wide load touches
-        if "TCP_TOTAL_ACCESSES_sum" in per and "TCP_TCC_READ_REQ_sum" in per and per["TCP_TOTAL_ACCESSES_sum"] > 0:
-            d["l1_hit_rate"] = 1.0 - per["TCP_TCC_READ_REQ_sum"] / per["TCP_TOTAL_ACCESSES_sum"]
+        cu_cycles = per["GRBM_GUI_ACTIVE"] / 8.0 * 256.0 if per.get("GRBM_GUI_ACTIVE") else None          # one texture-address unit and one L1 per CU
+        if "TA_TA_BUSY_sum" in per and cu_cycles:
+            d["ta_busy"] = per["TA_TA_BUSY_sum"] / cu_cycles
+        # where the vector memory path waits, as fractions of the CUs' cycles
+        for c, name in (("TCP_TCP_TA_DATA_STALL_CYCLES_sum", "tcp_ta_data_stall"), ("TCP_PENDING_STALL_CYCLES_sum", "tcp_pending_stall"),
+                        ("TA_ADDR_STALLED_BY_TC_CYCLES_sum", "ta_addr_stalled_by_tc"), ("TA_DATA_STALLED_BY_TC_CYCLES_sum", "ta_data_stalled_by_tc")):
+            if c in per and cu_cycles:
+                d[name] = per[c] / cu_cycles
+        # what one wave-wide instruction costs the L1, reads and writes apart (calibration: tools/ubench/l1_access.hip -- a coalesced dword access is
+        # 4 read / 4 write accesses... see profiles/*_l1_access_calibration.txt for the measured table)
+        if per.get("TCP_TOTAL_READ_sum") is not None and per.get("TA_FLAT_READ_WAVEFRONTS_sum"):
+            d["l1_reads_per_read_instruction"] = per["TCP_TOTAL_READ_sum"] / per["TA_FLAT_READ_WAVEFRONTS_sum"]
+        if per.get("TCP_TOTAL_WRITE_sum") is not None and per.get("TA_FLAT_WRITE_WAVEFRONTS_sum"):
+            d["l1_writes_per_write_instruction"] = per["TCP_TOTAL_WRITE_sum"] / per["TA_FLAT_WRITE_WAVEFRONTS_sum"]
+        if per.get("TCP_TOTAL_READ_sum") and "TCP_TCC_READ_REQ_sum" in per:
+            d["l1_read_hit_rate"] = 1.0 - per["TCP_TCC_READ_REQ_sum"] / per["TCP_TOTAL_READ_sum"]
+        # the measured instruction mix: wave-instructions per launch by class (tools/pmc_mix.py prints the same from its own passes)
+        if per.get("SQ_INSTS_VALU"):
+            typed = ["ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "INT64", "CVT"]
+            if all(("SQ_INSTS_VALU_" + t) in per for t in typed):
+                mix = {t.lower(): per["SQ_INSTS_VALU_" + t] for t in typed}
+                mix["other"] = per["SQ_INSTS_VALU"] - sum(mix.values())
+                mix["fp64_wave_instructions"] = sum(per["SQ_INSTS_VALU_" + t] for t in typed[:4])
+                mix["fp64_share_of_valu"] = mix["fp64_wave_instructions"] / per["SQ_INSTS_VALU"]
+                rec["instruction_mix_per_launch"] = mix
         if "SQ_THREAD_CYCLES_VALU" in per and per.get("SQ_ACTIVE_INST_VALU"):
             d["lane_utilisation"] = per["SQ_THREAD_CYCLES_VALU"] / (64.0 * per["SQ_ACTIVE_INST_VALU"])
         if per.get("SQ_WAVE_CYCLES"):
@@ -85,7 +100,8 @@ def main():
             d["l2_hit_rate"] = per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"])
         d["formulas"] = ("valu_wave_active_per_simd_cycle = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) (quad-cycles; > 1 possible for 32-bit code); "
                          "valu_issue_xN = SQ_INSTS_VALU x N / SIMD cycles; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait fractions over SQ_WAVE_CYCLES; "
-                         "ta_busy / tcp_busy / tcp_ta_data_stall = *_sum / (GRBM_GUI_ACTIVE / 8 x 256 CUs)")
+                         "ta_busy and the four stall fractions = *_sum / (GRBM_GUI_ACTIVE / 8 x 256 CUs); l1_reads_per_read_instruction = TCP_TOTAL_READ_sum / TA_FLAT_READ_WAVEFRONTS_sum, "
+                         "writes likewise (calibration: tools/ubench/l1_access.hip)")
         rec["derived"] = d
         if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
             rec["hbm_bytes_per_launch"] = (per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024.0

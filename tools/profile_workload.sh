@@ -2,7 +2,8 @@
 # Profiles of a bench workload for profiles/ (run on the GPU box from the repo root, e.g. through gpurun):
 #   1. rocprofv3 --kernel-trace --stats of `bench.py` with ONE batch lane (FRAYHIP_PT_LANES=1): every launch alone on the chip, so
 #      launches x average duration <= frame time and the averages are comparable with bench.py's serialised pass;
-#   2. separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ counters in sets of 8; the vector-memory path: TA / TCP),
+#   2. separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ counters in sets of 8; the vector-memory path: TA / TCP; the typed
+#      instruction counters: FP64 / FP32 add, mul, fma, transcendental, integer, conversions),
 #      kernel trace only, as the pool requires;
 #   3. tools/pmc_finish.py folds them into gpurun_out/prof_$TAG/pmc.json (+ the device code's source hash).
 # usage: tools/profile_workload.sh TAG [WORKLOAD] [quick]      (quick: the SQ and TA/TCP passes only)
@@ -20,8 +21,14 @@ echo "trace done" >> $OUT/progress.log
 SETS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU"
       "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM"
       "GRBM_GUI_ACTIVE GRBM_COUNT TCC_HIT_sum TCC_MISS_sum"
-      "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum"
-      "TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_GATE_EN1_sum")
+      # the vector memory path: how busy the texture-address unit is, what a read / a write instruction costs the L1 in accesses (read and write
+      # counted apart and calibrated by tools/ubench/l1_access.hip), and where the path waits (TCP_GATE_EN1, round 3's "tcp_busy", is a clock-gate
+      # enable: it read 0.975 for a kernel without a single vector load and is gone)
+      "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum TCP_TOTAL_READ_sum TCP_TOTAL_WRITE_sum TCP_TCC_READ_REQ_sum"
+      "TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
+      # the measured instruction mix (what tools/pmc_mix.sh collects on its own)
+      "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_BRANCH"
+      "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT")
 if [ -z "$QUICK" ]; then SETS+=("FETCH_SIZE" "WRITE_SIZE"); fi
 i=0
 for set in "${SETS[@]}"; do

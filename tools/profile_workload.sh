@@ -20,11 +20,11 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t
 echo "trace done" >> $OUT/progress.log
 SETS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU"
       "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM"
-      "GRBM_GUI_ACTIVE GRBM_COUNT TCC_HIT_sum TCC_MISS_sum"
+      "GRBM_GUI_ACTIVE GRBM_COUNT TCC_HIT_sum TCC_MISS_sum TA_FLAT_WRITE_WAVEFRONTS_sum TCP_TOTAL_WRITE_sum"
       # the vector memory path: how busy the texture-address unit is, what a read / a write instruction costs the L1 in accesses (read and write
       # counted apart and calibrated by tools/ubench/l1_access.hip), and where the path waits (TCP_GATE_EN1, round 3's "tcp_busy", is a clock-gate
       # enable: it read 0.975 for a kernel without a single vector load and is gone)
-      "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum TCP_TOTAL_READ_sum TCP_TOTAL_WRITE_sum TCP_TCC_READ_REQ_sum"
+      "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_READ_sum TCP_TCC_READ_REQ_sum"
       "TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
       # the measured instruction mix (what tools/pmc_mix.sh collects on its own)
       "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_BRANCH"
@@ -43,4 +43,5 @@ cat $OUT/pmc.txt
 # keep what profiles/ wants in a few small files (the per-pass directories stay on the box's scratch copy)
 cp "$(ls -t $OUT/trace/*/*_kernel_stats.csv | head -1)" $OUT/kernel_stats.csv 2>/dev/null || true
 cp "$(ls -t $OUT/trace/*/*_kernel_trace.csv | head -1)" $OUT/kernel_trace.csv 2>/dev/null || true
+mkdir -p $OUT/logs && cp $OUT/p[0-9]*.log $OUT/logs/ 2>/dev/null || true
 rm -rf $OUT/p[0-9]* $OUT/trace

@@ -11,7 +11,12 @@ INC     := -Iinclude -Ifray_amd/csrc
 # -mllvm -disable-machine-licm: MachineLICM hoists the FP64 constants of the inlined polynomials (acos, sin / cos, atan2) out of the
 # kernels' outer loops as VGPR pairs; the register allocator then spills them and every Horner step reloads one from scratch and waits
 # for it.  Without the pass k_pt_bounce needs 146 VGPRs and no scratch (168 + 68 spilled with it): headline frame 135.8 -> 126.9 ms.
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -mllvm -disable-machine-licm $(INC)
+# -mllvm -wwm-regalloc=basic: the registers that hold SPILLED SGPRs (VGPR lanes written in whole-wave mode) are assigned by a pass of their own, and its
+# default (greedy) allocator miscompiled round 3's Cube / CSG kernel variants: round 3's tree with SGPR spills in VGPR lanes renders 22 of 22 fuzz scenes wrong
+# (10-20 % of the pixels of every path-traced frame), the same tree with this flag renders all of them right, as it does with the spills sent to memory
+# (tools/repro/README.md).  Round 4's kernels no longer have what provoked it (out-of-line calls), but every big kernel here still spills SGPRs to lanes; the
+# basic allocator costs nothing measurable (headline 95.1 vs 95.5 ms, forest 12.33 vs 12.34, boxed 8.27 vs 8.33, dragon Whitted 16.3 vs 16.1, bokeh 69.8 vs 68.4).
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -mllvm -disable-machine-licm -mllvm -wwm-regalloc=basic $(INC)
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off $(INC)
 
 HOST_SRC := fray_amd/csrc/host_scene.cpp fray_amd/csrc/host_loaders.cpp fray_amd/csrc/host_exr.cpp fray_amd/csrc/capi_host.cpp

@@ -171,13 +171,18 @@ def test_build_recipe_keeps_what_correctness_depends_on(fray):
     """Build facts the pictures depend on.  (1) Round 3 compiled the Cube / CSG kernel variants with -amdgpu-spill-sgpr-to-vgpr=false
     because, with SGPR spills in VGPR lanes, two equivalent source changes made k_whitted<2> / k_pt_shadow<2> render wrong pictures; those variants
     were the only ones with out-of-line calls (sixteen CsgOp levels).  Round 4 rebuilt CsgOp::intersect as one loop over an explicit stack: NO device
-    function is called anywhere any more, the flag is gone, and both facts are checked here -- a call creeping back in must be a decision.  (2) The
+    function is called anywhere any more, the flag is gone, and both facts are checked here -- a call creeping back in must be a decision.  The cause was
+    narrowed down in round 4 (tools/repro/README.md): LLVM's greedy allocator for the VGPRs that hold spilled SGPRs; round 3's tree renders every Cube / CSG
+    fuzz scene wrong with it and right with -mllvm -wwm-regalloc=basic, which the whole library is now built with.  (2) The
     host code takes sine and cosine of an angle from ONE sincos() call like the reference's g++ build (clang would call sin() and cos(), whose sine
     differs in the last place for one angle in 700): the library must import sincos and neither sin nor cos."""
     import glob
     import re
     mk = open(os.path.join(ROOT, "Makefile")).read()
     assert "spill-sgpr-to-vgpr" not in mk
+    # the allocator of the VGPRs that hold spilled SGPRs: LLVM's default (greedy) one is what miscompiled round 3's kernels (tools/repro/README.md)
+    flags = [l for l in mk.splitlines() if l.startswith("HIPFLAGS")]
+    assert flags and "-mllvm -wwm-regalloc=basic" in flags[0]
     reports = sorted(glob.glob(os.path.join(ROOT, "fray_amd", "csrc", "variant*.resources.txt")))
     assert len(reports) == 8, reports
     for r in reports:

@@ -61,7 +61,7 @@ FD void prim_attributes(const DScene& S, int kind, int index, V3 ipl, int code, 
 
 // BARY: the hit record carries no barycentrics (the path tracer's hit queue): they are re-derived for meshes that read them.
 template <int ST, bool BARY = false>
-FD void finalize_hit(const DScene& S, const HitRec& h, V3 o, V3 d, bool needUV, HitInfo& info)
+FD void finalize_hit(const DScene& S, const HitT<ST>& h, V3 o, V3 d, bool needUV, HitInfo& info)
 {
     const FRAY_RO DNode& N = S.nodes[h.node];
     needUV = needUV && tex_variant(ST);                       // no texture in the scene reads (u, v)
@@ -73,13 +73,19 @@ FD void finalize_hit(const DScene& S, const HitRec& h, V3 o, V3 d, bool needUV, 
     info.dNdx = v3(0, 0, 0);
     info.dNdy = v3(0, 0, 0);
     info.u = 0; info.v = 0;
-    if ((ST & 2) && N.geomKind == 2) {
-        ipl = h.ipl;                                              // Cube::intersect's own ip and side, kept by closest_hit
-        prim_attributes(S, 2, N.geomIndex, ipl, h.tri, 0, 0, needUV, needBump, nl, info);
-    } else if ((ST & 2) && N.geomKind == 4) {
-        ipl = h.ipl;                                              // the winning intersection of CsgOp::intersect as its leaf geometry reported it
-        prim_attributes(S, h.leafKind, h.leafIndex, ipl, h.tri, h.l2, h.l3, needUV, needBump, nl, info);
-    } else {
+    bool done = false;
+    if constexpr ((ST & 2) != 0) {
+        if (N.geomKind == 2) {
+            ipl = h.ipl;                                          // Cube::intersect's own ip and side, kept by closest_hit
+            prim_attributes(S, 2, N.geomIndex, ipl, h.tri, 0, 0, needUV, needBump, nl, info);
+            done = true;
+        } else if (N.geomKind == 4) {
+            ipl = h.ipl;                                          // the winning intersection of CsgOp::intersect as its leaf geometry reported it
+            prim_attributes(S, h.leafKind, h.leafIndex, ipl, h.tri, h.l2, h.l3, needUV, needBump, nl, info);
+            done = true;
+        }
+    }
+    if (!done) {
         double l2 = h.l2, l3 = h.l3;
         if (BARY && N.geomKind == 3) {
             const FRAY_RO DMesh& M = S.meshes[N.geomIndex];

@@ -47,12 +47,19 @@ struct HitRec {
     double dist;    // world distance (Node::intersect's recomputed dist)
     double t;       // local ray parameter: plane `scaling`, sphere `dist`, triangle gamma
     double l2, l3;  // barycentrics (meshes)
-    // Cube / CSG nodes only (the <ST & 2> kernel variants; dead code elsewhere): the winning intersection as its geometry reported it --
-    // the local hit point (not ls + ld t for these two) and, for a CsgOp, the plain geometry at the bottom of the tree that produced it --
-    // so that finalize_hit does not have to run CsgOp::intersect a second time to learn them.
+};
+// The Cube / CSG kernel variants (<ST & 2>) carry more: the winning intersection as its geometry reported it -- the local hit point (not
+// ls + ld t for these two) and, for a CsgOp, the plain geometry at the bottom of the tree that produced it -- so that finalize_hit does not
+// have to run CsgOp::intersect a second time to learn them.  The other variants keep the six-field record (two more fields in it measured
+// +5 % on the wavefront's shade kernel: 6 more spilled VGPRs).
+struct HitRecX : HitRec {
     V3 ipl;
     int leafKind, leafIndex;
 };
+template <int ST> struct HitOf { typedef HitRec type; };
+template <> struct HitOf<2> { typedef HitRecX type; };
+template <> struct HitOf<3> { typedef HitRecX type; };
+template <int ST> using HitT = typename HitOf<ST>::type;
 
 struct Box6 { double lox, loy, loz, hix, hiy, hiz; };
 
@@ -380,7 +387,10 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
                 }
             }
 #endif
+            const int beg = kd[leaf].triBegin, cnt = kd[leaf].triCount;
             bool found = false;
+            const FRAY_RO DTri* lt = M.ltris + beg;
+            const FRAY_RO DTri32* lf = M.ltris32 + beg;
             // the ray as the certified triangle filter reads it (dev_tricert.hpp): FP32, relative to the mesh's reference point.  Made again in
             // every leaf (nine instructions) rather than kept in seven registers through the walk
             // (the empty asm keeps the optimiser from hoisting the conversions out of the walk's loop, where they would hold those registers)
@@ -389,9 +399,6 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
             const float s32x = (float)(hx - M.ref[0]), s32y = (float)(hy - M.ref[1]), s32z = (float)(hz - M.ref[2]);
             const float d32x = (float)hdx, d32y = (float)hdy, d32z = (float)hdz;
             const bool rayOk32 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(s32x), __builtin_fabsf(s32y)), __builtin_fabsf(s32z)) <= 1e9f;
-            const int beg = kd[leaf].triBegin, cnt = kd[leaf].triCount;
-            const FRAY_RO DTri* lt = M.ltris + beg;
-            const FRAY_RO DTri32* lf = M.ltris32 + beg;
             // two passes over (at most 32 at a time of) the leaf's triangles: the certified FP32 filter marks the ones the reference's test may
             // accept (dev_tricert.hpp: the others it surely rejects, and a rejected triangle leaves no trace), then the reference's arithmetic
             // runs on the marked ones in their order.  A wave spends its FP64 tests on max-over-lanes CANDIDATES instead of triangles.
@@ -636,8 +643,9 @@ FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win
 
 // Geometry part of Node::intersect for node N on the local ray; on a hit returns the local
 // intersection point and fills t / tri / l2 / l3.
+struct LeafOut { int kind, index; };     // Cube / CSG nodes only: the plain geometry at the bottom of the tree that produced the hit
 template <int ST>
-FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, LocalRay& lr, V3& ipl, double& t, int& tri, double& l2, double& l3, int& leafKind, int& leafIndex, Cnt& c)
+FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, LocalRay& lr, V3& ipl, double& t, int& tri, double& l2, double& l3, LeafOut* lo, Cnt& c)
 {
     const V3 ls = lr.s, ld = lr.d;
     if (N.geomKind == 0) {   // Plane::intersect, geometry.cpp:30-50
@@ -682,7 +690,7 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, L
         ipl = h.ip;
         tri = h.code;
         t = h.dist;
-        leafKind = 2; leafIndex = N.geomIndex;
+        lo->kind = 2; lo->index = N.geomIndex;
         return true;
     }
     if ((ST & 2) && N.geomKind == 4) {   // CSG: the winner is re-derived in finalize_hit
@@ -694,7 +702,7 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, L
         tri = h.code;
         t = h.dist;
         l2 = h.l2; l3 = h.l3;
-        leafKind = h.leafKind; leafIndex = h.leafIndex;
+        lo->kind = h.leafKind; lo->index = h.leafIndex;
         return true;
     }
     // mesh
@@ -737,7 +745,7 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, L
 
 // Node::intersect (geometry.cpp:196-208) reduced to what the closest-hit comparison needs.
 template <int ST>
-FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double& dist, double& t, int& tri, double& l2, double& l3, V3& ipl, int& leafKind, int& leafIndex, Cnt& c)
+FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double& dist, double& t, int& tri, double& l2, double& l3, V3* iplOut, LeafOut* lo, Cnt& c)
 {
     bump<ST>(c.node);
     const FRAY_RO DNode& N = S.nodes[i];
@@ -748,9 +756,11 @@ FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double&
         lr.haveRd = false;
     }
     STAMP(1);
-    const bool hit = geom_intersect<ST>(S, N, i, lr, ipl, t, tri, l2, l3, leafKind, leafIndex, c);
+    V3 ipl;
+    const bool hit = geom_intersect<ST>(S, N, i, lr, ipl, t, tri, l2, l3, lo, c);
     STAMP(5);             // whatever geom_intersect did not stamp itself: planes, spheres, the KD walk
     if (!hit) return false;
+    if constexpr ((ST & 2) != 0) { if (iplOut) *iplOut = ipl; }
     V3 ipw = mulM(ipl, N.T.m) + ld3(N.T.off);
     dist = length(o - ipw);
     STAMP(6);
@@ -779,7 +789,7 @@ FD bool light_intersect(const FRAY_RO DLight& L, V3 o, V3 d, double& dist, Cnt& 
 
 // The two loops of raytrace()/pathtrace(): first node wins ties (strict <), then lights.
 template <int ST>
-FD void closest_hit(const DScene& S, V3 o, V3 d, HitRec& best, Cnt& c)
+FD void closest_hit(const DScene& S, V3 o, V3 d, HitT<ST>& best, Cnt& c)
 {
     bump<ST>(c.closest);
     best.node = -1;
@@ -792,11 +802,17 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitRec& best, Cnt& c)
     lr.haveRd = false;
     for (int i = 0; i < nn; i++) {
         double dist, t, l2 = 0, l3 = 0;
-        int tri = -1, leafKind = 0, leafIndex = 0;
-        V3 ipl;
-        if (node_intersect<ST>(S, i, o, d, lr, dist, t, tri, l2, l3, ipl, leafKind, leafIndex, c) && dist < best.dist) {
+        int tri = -1;
+        if constexpr ((ST & 2) != 0) {
+            // Cube / CSG variants: the winning intersection as its geometry reported it travels with the hit record (finalize_hit)
+            V3 ipl;
+            LeafOut lo{0, 0};
+            if (node_intersect<ST>(S, i, o, d, lr, dist, t, tri, l2, l3, &ipl, &lo, c) && dist < best.dist) {
+                best.node = i; best.tri = tri; best.dist = dist; best.t = t; best.l2 = l2; best.l3 = l3;
+                best.ipl = ipl; best.leafKind = lo.kind; best.leafIndex = lo.index;
+            }
+        } else if (node_intersect<ST>(S, i, o, d, lr, dist, t, tri, l2, l3, nullptr, nullptr, c) && dist < best.dist) {
             best.node = i; best.tri = tri; best.dist = dist; best.t = t; best.l2 = l2; best.l3 = l3;
-            if constexpr ((ST & 2) != 0) { best.ipl = ipl; best.leafKind = leafKind; best.leafIndex = leafIndex; }
         }
     }
     if ((ST & 1) && best.node >= 0) {   // byte model: the winner's corner normals / uvs
@@ -832,9 +848,9 @@ FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c)
     lr.haveRd = false;
     for (int i = 0; i < nn; i++) {
         double dist, t, l2, l3;
-        int tri, leafKind, leafIndex;
-        V3 ipl;
-        if (node_intersect<ST>(S, i, a, d, lr, dist, t, tri, l2, l3, ipl, leafKind, leafIndex, c) && dist < maxDist) return false;
+        int tri;
+        LeafOut lo;
+        if (node_intersect<ST>(S, i, a, d, lr, dist, t, tri, l2, l3, nullptr, (ST & 2) ? &lo : nullptr, c) && dist < maxDist) return false;
     }
     return true;
 }

@@ -142,7 +142,7 @@ template <int ST>
 FD void wl_trace_step(const DScene& S, WhittedLane& L, Cnt& c)
 {
     if (L.depth > S.maxTraceDepth) { L.ret = c3(0, 0, 0); L.mode = WM_RET; return; }
-    HitRec h;
+    HitT<ST> h;
     closest_hit<ST>(S, L.o, L.d, h, c);
     if (h.node <= -2) { L.ret = light_color(S.lights[-2 - h.node]); L.mode = WM_RET; }
     else if (h.node < 0) { L.ret = environment<ST>(S, L.d, c); L.mode = WM_RET; }

@@ -222,7 +222,7 @@ static __global__ __launch_bounds__(256, primary_waves(ST)) void k_primary(Prima
         if (!item_pixel(F, item, x, y)) continue;
         V3 o, d;
         screen_ray(C, (double)x, (double)y, o, d);
-        HitRec h;
+        HitT<ST> h;
         closest_hit<ST>(S, o, d, h, c);
         size_t p = (size_t)y * F.W + x;
         int32_t* const hitId = KARG(PrimaryArgs, AP, hitId);
@@ -410,7 +410,7 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
 template <int ST>
 FD void wh_shade_eye(const DScene& S, V3 o, V3 d, MtLong& tab, const WhittedQueue& Q, size_t N, size_t e, Cnt& c)
 {
-    HitRec h;
+    HitT<ST> h;
     closest_hit<ST>(S, o, d, h, c);
     C3 base;
     unsigned char hit = 0;
@@ -849,7 +849,7 @@ FD void seg_advance(SegEnds& E, bool put, bool back)
 // segment sa -> sb carrying sc), the real spawnRay, the throughput update and the entry test of the next iteration
 // (`cont`: ps is the path to continue).
 template <int ST, bool BARY, class G>
-FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitRec& h, const TermBuf& TB, DStats* st, const StereoBuf& SB, bool& cont, bool& shadow, bool& shadowBack,
+FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitT<ST>& h, const TermBuf& TB, DStats* st, const StereoBuf& SB, bool& cont, bool& shadow, bool& shadowBack,
                    const ShadowQueue& SQ, const SegEndsShared& shadowEnds, Cnt& c)
 {
     C3 own = c3(0, 0, 0);          // this bounce's term, unless a queued next-event segment will provide it
@@ -969,7 +969,7 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
         if (live) {
             STAMP(0);
             // entry test of pathtrace() (main.cpp:173-176) was applied before this path was queued
-            HitRec h;
+            HitT<ST> h;
             closest_hit<ST>(S, ps.o, ps.d, h, c);
             if constexpr (FIRST) {
                 // the rest of the path's state, made after the search so that it is not live across it: the generators stand where the camera ray left them

@@ -245,7 +245,12 @@ static __constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0,
 // Persistent waves with PER-LANE refill: a lane that has finished its pixel takes the next one from the wave's pool (64 work items claimed
 // at a time from the XCD-affine cursors), so a lane whose pixel shows a 25-sample glossy floor does not keep 63 finished lanes waiting -- every
 // round of the machine has a closest-hit search to run for (nearly) every lane until the frame's items are gone.
-struct WhittedArgs { DScene S; DCamera C; DFrame F; int nItems; float* rgb; uint32_t* mtWork; const uint32_t* x397; DStats* st; DCursors* cur; };
+#ifdef FRAY_TILESTAT
+// diagnostic build only (tools/tilestat_run.sh): when did which wave hold which 8x8 tile?  [tile] = {start, end (s_memtime), global wave, kernel start}
+static __device__ unsigned long long g_tileStat[65536][8];   // + rounds, cheap-step iterations, lanes x rounds standing at a search, at a direct-light loop
+FD unsigned long long tile_now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; }
+#endif
+struct WhittedArgs { DScene S; DCamera C; DFrame F; int nItems; int s0, cn; float* rgb; float* rad; uint32_t* mtWork; const uint32_t* x397; DStats* st; DCursors* cur; };
 template <int ST>
 static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(WhittedArgs A)
 {
@@ -253,7 +258,11 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
     MtLong tab;
     tab.stride = gridDim.x * blockDim.x;
     tab.st = A.mtWork + (blockIdx.x * blockDim.x + threadIdx.x);
-    const int nItems = A.nItems;
+    // A work item is one camera sample: (pixel item, sample s0 + k), k-major, so that the 64 lanes of a wave hold the SAME sample of an 8x8 pixel
+    // tile and a pixel's samples -- independent given their seeds -- spread over the chip instead of queueing up in one lane (bokeh.fray,
+    // 640x480 with 45 lens samples: 4 800 tiles of 45 samples each for 3 072 waves left the chip 22 % occupied).  The per-pixel sum in
+    // sample order is k_pt_resolve's, as for the other integrators; a frame with one sample per pixel writes its pixel itself.
+    const int nItems = A.nItems, nTot = A.nItems * A.cn;
     DCursors* const cur = A.cur;
     DStats* const st = A.st;
     const uint32_t lane = threadIdx.x & 63u;
@@ -261,14 +270,19 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
     WhittedLane L;
     L.mode = WM_NEXT_PIXEL; L.sp = 0;
     // the lane's pixel and camera sample
-    int item = 0, x = 0, y = 0, i = 0, eye = 0;
-    C3 avg = c3(0, 0, 0), cl = c3(0, 0, 0);
+    int item = 0, x = 0, y = 0, k = 0, eye = 0;
+    C3 cl = c3(0, 0, 0);
     bool ovf = false;
     Mt rnd = tab.r;
     // the wave's pool of claimed work items [poolNext, poolEnd) and the claim state (wave-uniform)
     int poolNext = 0, poolEnd = 0, claimR = 0;
 #ifdef FRAY_STAMPS
     stamp_begin();
+#endif
+#ifdef FRAY_TILESTAT
+    const unsigned long long tsKernel = tile_now();
+    int tsTile = -1;
+    unsigned long long tsRounds = 0, tsCheap = 0, tsTrace = 0, tsDirect = 0;
 #endif
     for (;;) {
         const FRAY_RO WhittedArgs* AP = kernel_args<WhittedArgs>();
@@ -290,6 +304,9 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
             }
             const bool cheap = L.mode == WM_NEXT_PIXEL ? refill : (L.mode == WM_ROOT_RET || L.mode == WM_NEXT_SAMPLE || (L.mode < WM_ROOT_RET && wl_cheap(S, L)));
             if (!__any(cheap)) break;
+#ifdef FRAY_TILESTAT
+            tsCheap++;
+#endif
             // work items for the lanes that need a pixel: from the wave's pool, refilled one 8x8 tile at a time
             if (refill) {
                 if (poolNext == poolEnd && claimR < 8) {
@@ -305,19 +322,29 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
                         }
                     }
 #endif
-                    const int first = claim_items(cur, nItems, claimR);       // this lane's item of the claimed tile; nItems on every lane when nothing is left
-                    int base = __builtin_amdgcn_readfirstlane(first - (int)lane);
-#ifdef FRAY_EXP_REVERSE
-                    if (base < nItems) base = nItems - 64 - base;
+                    const int first = claim_items(cur, nTot, claimR);         // this lane's item of the claimed tile; nTot on every lane when nothing is left
+                    const int base = __builtin_amdgcn_readfirstlane(first - (int)lane);
+                    if (base < nTot) { poolNext = base; poolEnd = base + 64; }
+#ifdef FRAY_TILESTAT
+                    {
+                        const unsigned long long t = tile_now();
+                        if (lane == 0) {
+                            if (tsTile >= 0 && tsTile < 65536) { g_tileStat[tsTile][1] = t; g_tileStat[tsTile][4] = tsRounds; g_tileStat[tsTile][5] = tsCheap; g_tileStat[tsTile][6] = tsTrace; g_tileStat[tsTile][7] = tsDirect; }
+                            tsRounds = tsCheap = tsTrace = tsDirect = 0;
+                            tsTile = base < nTot ? base / 64 : -1;
+                            if (tsTile >= 0 && tsTile < 65536) { g_tileStat[tsTile][0] = t; g_tileStat[tsTile][2] = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; g_tileStat[tsTile][3] = tsKernel; }
+                        }
+                    }
 #endif
-                    if (base < nItems) { poolNext = base; poolEnd = base + 64; }
                 }
                 const int have = poolEnd - poolNext;
                 const int rank = (int)__popcll(need & ((1ull << lane) - 1ull));
                 if (L.mode == WM_NEXT_PIXEL) {
                     if (rank < have) {
-                        item = poolNext + rank;
-                        if (item_pixel(F, item, x, y)) { i = 0; avg = c3(0, 0, 0); L.mode = WM_NEXT_SAMPLE; }
+                        const int slot = poolNext + rank;
+                        k = slot / nItems;                                     // wave-uniform: nItems is a multiple of 64
+                        item = slot - k * nItems;
+                        if (item_pixel(F, item, x, y)) L.mode = WM_NEXT_SAMPLE;
                         // a slot of a ragged edge bucket outside the frame: nothing to render, ask again
                     } else if (have == 0 && claimR >= 8) {
                         L.mode = WM_EXHAUSTED;
@@ -327,16 +354,11 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
                 poolNext += want < have ? want : have;
             }
             if (L.mode == WM_NEXT_SAMPLE) {
-                if (i == F.spp) {                                            // vfb[y][x] = sum / spp, main.cpp:360
-                    avg = avg / (float)F.spp;
-                    const size_t q = ((size_t)y * F.W + x) * 3;
-                    float* const rgb = KARG(WhittedArgs, AP, rgb);
-                    rgb[q] = avg.r; rgb[q + 1] = avg.g; rgb[q + 2] = avg.b;
-                    L.mode = WM_NEXT_PIXEL;
-                } else {
+                {
+                    const int i = KARG(WhittedArgs, AP, s0) + k;
                     const uint32_t* const x397 = KARG(WhittedArgs, AP, x397);
                     const uint32_t p = (uint32_t)y * (uint32_t)F.W + (uint32_t)x;
-                    tab.reseed_with(sample_seed(F.seed, p, (uint32_t)i), x397[(size_t)i * nItems + item]);
+                    tab.reseed_with(sample_seed(F.seed, p, (uint32_t)i), x397[(size_t)k * nItems + item]);
                     rnd = tab.r;
                     float ox, oy;
                     if (F.jitter) { ox = rng_float(rnd); oy = rng_float(rnd); }
@@ -365,6 +387,7 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
                     wl_start(L, v3(rightRay[0][threadIdx.x], rightRay[1][threadIdx.x], rightRay[2][threadIdx.x]),
                              v3(rightRay[3][threadIdx.x], rightRay[4][threadIdx.x], rightRay[5][threadIdx.x]));
                 } else {
+                    C3 smp = L.ret;                                           // this camera sample's colour
                     if (stereo) {
                         C3 cr = L.ret;
                         if (S.saturation != 1) {                              // Color::adjustSaturation, color.h:127-133
@@ -372,13 +395,20 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
                             cl = c3(ml + (cl.r - ml) * S.saturation, ml + (cl.g - ml) * S.saturation, ml + (cl.b - ml) * S.saturation);
                             cr = c3(mr + (cr.r - mr) * S.saturation, mr + (cr.g - mr) * S.saturation, mr + (cr.b - mr) * S.saturation);
                         }
-                        avg = avg + (cl * ldc(C.leftMask) + cr * ldc(C.rightMask));
-                    } else {
-                        avg = avg + L.ret;
+                        smp = cl * ldc(C.leftMask) + cr * ldc(C.rightMask);
                     }
                     ovf = ovf || rnd.j > 227;
-                    i++;
-                    L.mode = WM_NEXT_SAMPLE;
+                    if (F.spp == 1) {                                         // vfb[y][x] = (0 + sample) / 1, main.cpp:348-360
+                        const C3 avg = (c3(0, 0, 0) + smp) / 1.0f;
+                        const size_t q = ((size_t)y * F.W + x) * 3;
+                        float* const rgb = KARG(WhittedArgs, AP, rgb);
+                        rgb[q] = avg.r; rgb[q + 1] = avg.g; rgb[q + 2] = avg.b;
+                    } else {                                                  // k_pt_resolve adds the pixel's samples in their order
+                        float* const rad = KARG(WhittedArgs, AP, rad);
+                        const size_t q = ((size_t)k * nItems + item) * 3;
+                        rad[q] = smp.r; rad[q + 1] = smp.g; rad[q + 2] = smp.b;
+                    }
+                    L.mode = WM_NEXT_PIXEL;
                 }
             } else if (L.mode < WM_ROOT_RET && wl_cheap(S, L)) {
                 wl_cheap_step<ST, MtLong>(S, L, tab, c, ovf);
@@ -386,6 +416,9 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
         }
         STAMP(12);
         if (!__any(L.mode != WM_EXHAUSTED)) break;
+#ifdef FRAY_TILESTAT
+        tsRounds++; tsTrace += __popcll(__ballot(L.mode == WM_TRACE)); tsDirect += __popcll(__ballot(L.mode == WM_SHADE));
+#endif
         if (L.mode == WM_TRACE) wl_trace_step<ST>(S, L, c);
         STAMP(14);
         if (L.mode == WM_SHADE && S.shaders[L.shader].kind <= 2) wl_direct_step<ST, MtLong>(S, L, tab, c);

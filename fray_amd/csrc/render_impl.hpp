@@ -98,20 +98,43 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
         } else if (!set.gi) {
             if (!F.jitter && spp > 5) { set_error("frayhip_render: bad sample count"); return FRAYHIP_E_ARG; }
             if (nItems > 0 && sc->whittedNeedsRecursion) {
-                // workspace: per-thread mt19937 state columns for samples that draw more than 227 words,
-                // then x[397] of every (pixel, sample) seed
-                const int grid = persistent_grid(nItems, whitted_waves(ST));
-                const size_t colBytes = ((size_t)grid * 256 * 624 * sizeof(uint32_t) + 255) / 256 * 256;
-                int rc = ensure_work(sc, colBytes + (size_t)nItems * spp * sizeof(uint32_t));
-                if (rc) return rc;
-                uint32_t* x397 = (uint32_t*)((unsigned char*)sc->d_work + colBytes);
-                hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * spp + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, 0, spp, x397);
-                hipEvent_t a = pool_event(sc->evPool, 0), b = pool_event(sc->evPool, 1);
-                if (!a || !b) return FRAYHIP_E_NOMEM;
-                HIP_TRY(hipEventRecord(a, stream));
-                hipLaunchKernelGGL(k_whitted<ST>, dim3(grid), dim3(256), 0, stream, WhittedArgs{S, C, F, nItems, d_rgb, (uint32_t*)sc->d_work, x397, sc->d_stats, cursors});
-                HIP_TRY(hipEventRecord(b, stream));
-                nTraceEvents = 2;
+                // workspace: per-thread mt19937 state columns for samples that draw more than 227 words, the pixels' running sums, then per
+                // (pixel, sample) of a batch the sample's colour and x[397] of its seed.  A work item of k_whitted is one camera sample, so the
+                // grid is sized by the samples, and a frame whose samples do not fit the budget (or 2^31 items) is rendered in batches of `chunk` samples per pixel.
+                auto r256 = [](size_t b) { return (b + 255) / 256 * 256; };
+                const int grid = persistent_grid((size_t)nItems * spp, whitted_waves(ST));
+                const size_t colBytes = r256((size_t)grid * 256 * 624 * sizeof(uint32_t));
+                int chunk = 0;
+                for (;;) {          // planned again with half the budget when the allocation fails (ensure_work_or_shrink)
+                    const size_t wb = work_budget(sc);
+                    const size_t budget = wb > colBytes + (64u << 20) ? wb - colBytes : (64u << 20);
+                    chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / ((size_t)nItems * 16));
+                    if (chunk > spp) chunk = spp;
+                    while (chunk > 1 && (size_t)nItems * chunk >= ((size_t)1 << 31)) chunk /= 2;
+                    const size_t slots = (size_t)nItems * chunk;
+                    const int rc = ensure_work_or_shrink(sc, colBytes + r256((size_t)nItems * 12) + r256(slots * 12) + r256(slots * 4));
+                    if (rc == FRAYHIP_RETRY_SMALLER && f->spp_chunk <= 0 && chunk > 1) continue;
+                    if (rc) { if (rc == FRAYHIP_RETRY_SMALLER) return FRAYHIP_E_NOMEM; return rc; }
+                    break;
+                }
+                unsigned char* p = (unsigned char*)sc->d_work;
+                auto take = [&](size_t b) { unsigned char* r = p; p += r256(b); return r; };
+                uint32_t* mtWork = (uint32_t*)take(colBytes);
+                float* sum = (float*)take((size_t)nItems * 12);
+                float* rad = (float*)take((size_t)nItems * chunk * 12);
+                uint32_t* x397 = (uint32_t*)take((size_t)nItems * chunk * 4);
+                for (int s0 = 0; s0 < spp; s0 += chunk) {
+                    const int cn = std::min(chunk, spp - s0);
+                    if (s0 > 0) HIP_TRY(hipMemsetAsync(cursors, 0, sizeof(DCursors), stream));      // the tile cursors of the previous batch
+                    hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * cn + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
+                    hipEvent_t a = pool_event(sc->evPool, nTraceEvents), b = pool_event(sc->evPool, nTraceEvents + 1);
+                    if (!a || !b) return FRAYHIP_E_NOMEM;
+                    HIP_TRY(hipEventRecord(a, stream));
+                    hipLaunchKernelGGL(k_whitted<ST>, dim3(grid), dim3(256), 0, stream, WhittedArgs{S, C, F, nItems, s0, cn, d_rgb, rad, mtWork, x397, sc->d_stats, cursors});
+                    HIP_TRY(hipEventRecord(b, stream));
+                    nTraceEvents += 2;
+                    if (spp > 1) hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, stream, F, C, set.saturation, nItems, s0, cn, rad, (const float*)nullptr, sum, d_rgb);
+                }
             } else if (nItems > 0) {
                 // Wavefront Whitted (no recursive shader in the scene): batches of `chunk` samples per pixel through
                 // k_wh_shade -> k_wh_visible -> k_wh_gather, then the ordered per-pixel sum (k_pt_resolve).
@@ -322,6 +345,13 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_leafStat), zero, sizeof zero);
         if (ls[0]) fprintf(stderr, "[leafstat] wave leaf phases %llu, all active lanes in ONE leaf %.1f %%, active lanes per phase %.1f, distinct leaves per phase %.2f\n",
                            ls[0], 100.0 * (double)ls[1] / (double)ls[0], (double)ls[2] / (double)ls[0], (double)ls[3] / (double)ls[0]);
+    }
+#endif
+#ifdef FRAY_TILESTAT
+    if (const char* out = getenv("FRAY_TILESTAT_OUT")) {
+        std::vector<unsigned long long> ts(65536 * 8);
+        (void)hipMemcpyFromSymbol(ts.data(), HIP_SYMBOL(g_tileStat), ts.size() * sizeof(unsigned long long));
+        if (FILE* fp = fopen(out, "wb")) { fwrite(ts.data(), sizeof(unsigned long long), ts.size(), fp); fclose(fp); }
     }
 #endif
 #ifdef FRAY_STAMPS

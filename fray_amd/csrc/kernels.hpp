@@ -100,9 +100,9 @@ FD bool item_pixel(const DFrame& F, int item, int& x, int& y)
 // turn.  One cursor for the whole frame would serialise ~30 k atomics on one address (~6 ns each),
 // which a 0.25 ms frame notices; eight run in parallel.  `r` counts the ranges this wave has seen
 // exhausted (start at 0); after the eighth the wave leaves, so the grid always drains.
-FD int claim_items(DCursors* cur, int nItems, int& r)
+FD int claim_tile(DCursors* cur, int nTiles, int& r)            // a 64-item tile for this wave, or -1 (wave-uniform)
 {
-    const int nTiles = nItems >> 6, per = (nTiles + 7) >> 3;
+    const int per = (nTiles + 7) >> 3;
     const int home = (int)(blockIdx.x & 7);
     while (r < 8) {
         const int range = (home + r) & 7;
@@ -110,10 +110,25 @@ FD int claim_items(DCursors* cur, int nItems, int& r)
         if ((threadIdx.x & 63) == 0) t = atomicAdd(&cur->v[range][0], 1u);
         t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
         const int tile = range * per + (int)t;
-        if (t < (unsigned int)per && tile < nTiles) return tile * 64 + (int)(threadIdx.x & 63);
+        if (t < (unsigned int)per && tile < nTiles) return tile;
         r++;
     }
-    return nItems;
+    return -1;
+}
+// The same for kernels whose launches may be small: with `cur` null the wave walks the tiles with a fixed stride instead (a frame of a few tiles per
+// wave pays more for the atomics -- ~30 k of them on eight addresses, and eight failing ones per wave at the end -- than it can win from balance:
+// zaphod 800x600, 0.31 ms with the stride, 0.45 ms with claims).  `tile` is the wave's previous tile, -1 at the start.
+FD int next_tile(DCursors* cur, int nTiles, int& r, int tile)
+{
+    if (cur) return claim_tile(cur, nTiles, r);
+    const int w = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nW = (int)((gridDim.x * blockDim.x) >> 6);
+    tile = tile < 0 ? w : tile + nW;
+    return tile < nTiles ? tile : -1;
+}
+FD int claim_items(DCursors* cur, int nItems, int& r)
+{
+    const int tile = claim_tile(cur, nItems >> 6, r);
+    return tile < 0 ? nItems : tile * 64 + (int)(threadIdx.x & 63);
 }
 
 FD void flush_stats(DStats* st, const Cnt& c)
@@ -497,7 +512,7 @@ FD void wh_shade_eye(const DScene& S, V3 o, V3 d, MtLong& tab, const WhittedQueu
     Q.hit[e] = hit;
 }
 
-struct WhShadeArgs { DScene S; DCamera C; DFrame F; int nItems, s0, chunk; WhittedQueue Q; uint32_t* mtWork; const uint32_t* x397; DStats* st; };
+struct WhShadeArgs { DScene S; DCamera C; DFrame F; int nItems, s0, chunk; WhittedQueue Q; uint32_t* mtWork; const uint32_t* x397; DStats* st; DCursors* cur; };
 template <int ST>
 static __global__ __launch_bounds__(256, waves_for(ST, FRAY_WH_SHADE_WAVES)) void k_wh_shade(WhShadeArgs A)
 {
@@ -515,7 +530,11 @@ static __global__ __launch_bounds__(256, waves_for(ST, FRAY_WH_SHADE_WAVES)) voi
 #ifdef FRAY_STAMPS
     stamp_begin();
 #endif
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += gridDim.x * blockDim.x) {
+    // persistent waves claiming 64-slot tiles (next_tile; total is a multiple of 64): with a fixed stride from slot to slot the waves that drew the picture's expensive tiles
+    // finished last and the chip stood 18-23 % empty (forest DOF: 3.1-3.3 of 4 waves per SIMD resident on average)
+    DCursors* const cur = A.cur;
+    for (int r = 0, tile = next_tile(cur, (int)(total >> 6), r, -1); tile >= 0; tile = next_tile(cur, (int)(total >> 6), r, tile)) {
+        const uint32_t slot = (uint32_t)tile * 64u + (threadIdx.x & 63u);
         STAMP(13);
         const FRAY_RO WhShadeArgs* AP = kernel_args<WhShadeArgs>();
         const DScene& S = KARG(WhShadeArgs, AP, S);
@@ -573,7 +592,7 @@ static __global__ __launch_bounds__(256, waves_for(ST, FRAY_WH_SHADE_WAVES)) voi
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
 
-struct WhVisibleArgs { DScene S; WhittedQueue Q; size_t N; int T; DStats* st; };
+struct WhVisibleArgs { DScene S; WhittedQueue Q; size_t N; int T; DStats* st; DCursors* cur; };
 template <int ST>
 static __global__ __launch_bounds__(256, anyhit_waves(ST)) void k_wh_visible(WhVisibleArgs A)
 {
@@ -584,7 +603,12 @@ static __global__ __launch_bounds__(256, anyhit_waves(ST)) void k_wh_visible(WhV
 #ifdef FRAY_STAMPS
     stamp_begin();
 #endif
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    // persistent waves claiming 64-test tiles, as k_wh_shade does (total <= 2^31: render_impl's batch size)
+    DCursors* const cur = A.cur;
+    const int nTiles = (int)((total + 63) >> 6);
+    for (int r = 0, tile = next_tile(cur, nTiles, r, -1); tile >= 0; tile = next_tile(cur, nTiles, r, tile)) {
+        const size_t t = (size_t)tile * 64 + (threadIdx.x & 63);
+        if (t >= total) continue;
         STAMP(13);
         const FRAY_RO WhVisibleArgs* AP = kernel_args<WhVisibleArgs>();
         const DScene& S = KARG(WhVisibleArgs, AP, S);

@@ -184,11 +184,16 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
                     if (!ea || !eb || !ec || !ed) return FRAYHIP_E_NOMEM;
                     HIP_TRY(hipEventRecord(ea, stream));
-                    hipLaunchKernelGGL(k_wh_shade<ST>, dim3(grid), dim3(256), 0, stream, WhShadeArgs{S, C, F, nItems, s0, cn, Q, mtWork, x397, sc->d_stats});
+                    if (s0 > 0) HIP_TRY(hipMemsetAsync(cursors, 0, 2 * sizeof(DCursors), stream));        // the previous batch's tile cursors (one set per kernel)
+                    // tiles are claimed when a wave gets at least 32 of them, walked with a fixed stride otherwise (next_tile, kernels.hpp)
+                    const bool claimShade = bs / 64 >= (size_t)grid * 4 * 32;
+                    const int gridVis = persistent_grid(bN * (size_t)T, anyhit_waves(ST));
+                    const bool claimVis = (bN * (size_t)T) / 64 >= (size_t)gridVis * 4 * 32;
+                    hipLaunchKernelGGL(k_wh_shade<ST>, dim3(grid), dim3(256), 0, stream, WhShadeArgs{S, C, F, nItems, s0, cn, Q, mtWork, x397, sc->d_stats, claimShade ? cursors : nullptr});
                     HIP_TRY(hipEventRecord(eb, stream));
                     nTraceEvents += 2;
                     HIP_TRY(hipEventRecord(ec, stream));
-                    if (T > 0) hipLaunchKernelGGL(k_wh_visible<ST>, dim3(grid_for(bN * (size_t)T)), dim3(256), 0, stream, WhVisibleArgs{S, Q, bN, T, sc->d_stats + 1});
+                    if (T > 0) hipLaunchKernelGGL(k_wh_visible<ST>, dim3(gridVis), dim3(256), 0, stream, WhVisibleArgs{S, Q, bN, T, sc->d_stats + 1, claimVis ? cursors + 1 : nullptr});
                     HIP_TRY(hipEventRecord(ed, stream));
                     nShadowEvents += 2;
                     hipLaunchKernelGGL(k_wh_gather, dim3(grid_for(bN)), dim3(256), 0, stream, S, Q, bN, bs, radL, radR);

@@ -74,7 +74,7 @@ namespace frayhip_detail {
 
 // d_stats: two DStats blocks, then (256-byte aligned) the work cursors; one memset clears all of it per frame
 constexpr size_t kCursorOffset = (2 * sizeof(DStats) + 255) / 256 * 256;
-constexpr size_t kStatsBytes = kCursorOffset + sizeof(DCursors);
+constexpr size_t kStatsBytes = kCursorOffset + 2 * sizeof(DCursors);     // two sets of tile cursors: a batch's closest-hit and any-hit kernels
 
 DCamera camera_begin_frame(const frayhip_camera& c, int W, int H);
 int persistent_grid(size_t n, int wavesPerSimd);

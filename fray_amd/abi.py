@@ -162,6 +162,7 @@ SYMBOLS = {
     "frayhip_scene_destroy": (None, [VP]),
     "frayhip_scene_set_view": (C.c_int, [VP, P(Camera), P(Settings)]),
     "frayhip_scene_set_option": (C.c_int, [VP, C.c_char_p, i64]),
+    "frayhip_scene_get_option": (C.c_int, [VP, C.c_char_p, P(i64)]),
     "frayhip_render": (C.c_int, [VP, P(Frame), VP, VP, VP, P(Stats)]),
     "frayhip_render_device": (C.c_int, [VP, P(Frame), VP, VP, VP, VP, P(Stats)]),
     "frayhip_bucket_count": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -511,6 +511,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     }
     size_t oLayers = A.add(layers.data(), layers.size() * sizeof(DLayer));
     std::vector<DLight> lights(d.n_lights);
+    bool anyLightDraws = false;
     for (int i = 0; i < d.n_lights; i++) {
         const frayhip_light& l = d.lights[i];
         DLight& o = lights[i];
@@ -522,9 +523,16 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         put3(o.center, l.center);
         o.area = l.area;
         sc->lightSampleCount += l.kind == FRAYHIP_LIGHT_RECT ? l.xSubd * l.ySubd : 1;
+        if (l.kind == FRAYHIP_LIGHT_RECT) anyLightDraws = true;          // RectLight::getNthSample draws two words per sample (lights.cpp:62-63)
         o.areaXsize = 1.0 / l.xSubd;
         o.areaYsize = 1.0 / l.ySubd;
     }
+    // glossy fans may be drawn ahead (dev_whitted.hpp) where nothing under them is likely to draw: no light that samples, a fan of eight or more
+    sc->specFanMax = 0;
+    if (!anyLightDraws)
+        for (int i = 0; i < d.n_shaders; i++)
+            if (d.shaders[i].kind == FRAYHIP_SHADER_REFL && d.shaders[i].glossiness != 1.0 && d.shaders[i].numSamples >= 8)
+                sc->specFanMax = std::max(sc->specFanMax, (int)d.shaders[i].numSamples);
     size_t oLights = A.add(lights.data(), lights.size() * sizeof(DLight));
     size_t oMeshes = A.add(nullptr, 0);              // reserve aligned slots for the tables that hold device pointers
     A.host.resize(oMeshes + meshes.size() * sizeof(DMesh));
@@ -627,8 +635,24 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     }
     // profiling aids: the same knobs as frayhip_scene_set_option, preset from the environment
     if (const char* e = getenv("FRAYHIP_PT_LANES")) { long v = atol(e); if (v >= 1 && v <= FRAY_PT_LANES) sc->ptLanes = (int)v; }
+    if (const char* e = getenv("FRAYHIP_SPECULATE_FANS")) sc->speculateFans = atol(e) != 0;
     if (const char* e = getenv("FRAYHIP_PT_BUDGET_MIB")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) { sc->ptBudgetBytes = (size_t)v << 20; sc->ptBudgetEff = 0; } }
     *out = sc;
+    return FRAYHIP_OK;
+}
+
+int frayhip_scene_get_option(frayhip_scene* s, const char* name, int64_t* value)
+{
+    if (!s || !name || !value) { set_error("frayhip_scene_get_option: null argument"); return FRAYHIP_E_ARG; }
+    const std::string n(name);
+    if (n == "pt_lanes") *value = s->ptLanes;
+    else if (n == "pt_budget_mib") *value = (int64_t)(s->ptBudgetBytes >> 20);
+    else if (n == "speculate_fans") *value = s->speculateFans ? 1 : 0;
+    else if (n == "fans_filed") *value = s->lastFans[0];
+    else if (n == "fan_children") *value = s->lastFans[1];
+    else if (n == "fan_children_looked_up") *value = s->lastFans[2];
+    else if (n == "fans_given_up") *value = s->lastFans[3];
+    else { set_error("frayhip_scene_get_option: unknown option " + n); return FRAYHIP_E_ARG; }
     return FRAYHIP_OK;
 }
 
@@ -643,6 +667,9 @@ int frayhip_scene_set_option(frayhip_scene* s, const char* name, int64_t value)
         if (value < 1 || value > (1 << 20)) { set_error("frayhip_scene_set_option: pt_budget_mib must be 1..1048576"); return FRAYHIP_E_ARG; }
         s->ptBudgetBytes = (size_t)value << 20;
         s->ptBudgetEff = 0;                 // clamp again at the next frame
+    } else if (n == "speculate_fans") {
+        if (value != 0 && value != 1) { set_error("frayhip_scene_set_option: speculate_fans must be 0 or 1"); return FRAYHIP_E_ARG; }
+        s->speculateFans = value != 0;
     } else {
         set_error("frayhip_scene_set_option: unknown option " + n);
         return FRAYHIP_E_ARG;

@@ -25,7 +25,7 @@ struct WFrame {
 // recursive shaders) until each stands at a closest-hit search (WM_TRACE), at a direct-light loop (WM_SHADE of a Constant / Lambert /
 // Phong surface) or at the end of its camera ray (WM_ROOT_RET); then ONE search runs for the whole wave, then ONE direct-light loop.
 // A lane's own sequence of steps, random draws and FP32 colour operations is the reference's depth-first call tree.
-enum { WM_TRACE = 0, WM_SHADE = 1, WM_RET = 2, WM_RESUME = 3, WM_ROOT_RET = 4, WM_NEXT_SAMPLE = 5, WM_NEXT_PIXEL = 6, WM_EXHAUSTED = 7 };
+enum { WM_TRACE = 0, WM_SHADE = 1, WM_RET = 2, WM_RESUME = 3, WM_ROOT_RET = 4, WM_NEXT_SAMPLE = 5, WM_NEXT_PIXEL = 6, WM_EXHAUSTED = 7, WM_DEFER = 8 };
 struct WhittedLane {
     WFrame stack[FRAY_WSTACK];
     int sp;
@@ -35,6 +35,22 @@ struct WhittedLane {
     int shader;
     C3 ret;
     int mode;
+};
+
+struct SpecBuf {
+    int* counters;                    // [0] entries, [1] children; after pass C [2] children looked up, [3] fans given up at a child that drew
+    int minCount;                     // fans of at least this many samples are filed
+    int* eSlot; int* eChildBase;      // per entry: the work item (k * nItems + pixel item), its first child
+    double* eo[3];                    //            the children's common origin
+    int* cEntry; double* cd[3];       // per child: its entry, its direction
+    float* cc[3]; unsigned char* cok; //            its colour; 1 = traced without a draw
+};
+struct SpecLane { int state, sp, base, looked, missed; };      // 0 = armed, 1 = the fan on stack level sp is being looked up from child `base`, 2 = off until the next sample
+
+// the generator of pass B: reports that it was asked, and returns words that differ so that no rejection loop spins on them
+struct MtSpy {
+    uint32_t x; bool used;
+    FD uint32_t next() { used = true; x = x * 747796405u + 2891336453u; return x ^ (x >> 15); }
 };
 
 FD void wl_start(WhittedLane& L, V3 o, V3 d)
@@ -47,8 +63,8 @@ FD bool wl_cheap(const DScene& S, const WhittedLane& L)
     return L.mode == WM_RET || L.mode == WM_RESUME || (L.mode == WM_SHADE && S.shaders[L.shader].kind >= 3);
 }
 
-template <int ST, class G>
-FD void wl_cheap_step(const DScene& S, WhittedLane& L, G& tab, Cnt& c, bool& overflow)
+template <int ST, class G, int MODE>
+FD void wl_cheap_step(const DScene& S, WhittedLane& L, G& tab, Cnt& c, bool& overflow, const SpecBuf& SP, SpecLane& SL)
 {
     if (L.mode == WM_SHADE) {                              // shader->shade(ray, info) of a recursive shader: push its activation
         const FRAY_RO DShader& sh = S.shaders[L.shader];
@@ -70,6 +86,11 @@ FD void wl_cheap_step(const DScene& S, WhittedLane& L, G& tab, Cnt& c, bool& ove
                 f.count = L.depth == 0 ? sh.numSamples : 3;    // LOW_GLOSSY_SAMPLES, constants.h:36
                 L.sp++;
                 L.mode = WM_RESUME;
+                // the camera sample's first depth-0 fan: filed by pass A, looked up by pass C (the same test in both: they reach it by the same steps)
+                if ((MODE == 1 || MODE == 3) && L.depth == 0 && f.count >= SP.minCount && SL.state == 0) {
+                    if (MODE == 1) L.mode = WM_DEFER;
+                    else { SL.state = 1; SL.sp = L.sp - 1; }
+                }
             }
             return;
         }
@@ -108,7 +129,10 @@ FD void wl_cheap_step(const DScene& S, WhittedLane& L, G& tab, Cnt& c, bool& ove
     WFrame& f = L.stack[L.sp - 1];
     const FRAY_RO DShader& sh = S.shaders[f.shader];
     if (f.kind == WF_GLOSSY) {                             // shading.cpp:172-204
-        if (f.i == f.count) { L.ret = f.acc / (float)f.count; L.sp--; L.mode = WM_RET; return; }
+        if (f.i == f.count) {
+            if (MODE == 3 && SL.state == 1 && SL.sp == L.sp - 1) SL.state = 2;
+            L.ret = f.acc / (float)f.count; L.sp--; L.mode = WM_RET; return;
+        }
         V3 n = faceforward(f.d, f.info.norm);
         V3 b, cc;
         orthonormalSystem(n, b, cc);
@@ -121,6 +145,12 @@ FD void wl_cheap_step(const DScene& S, WhittedLane& L, G& tab, Cnt& c, bool& ove
             V3 nn = normalized(n + b * x + cc * y);
             reflected = reflect(f.d, nn);
             if (dot(reflected, n) > 0) break;
+        }
+        if (MODE == 3 && SL.state == 1 && SL.sp == L.sp - 1) {  // the filed fan: this child's raytrace() ran in pass B, from this very ray, unless a draw came in between
+            const int ch = SL.base + f.i;
+            if (SP.cok[ch]) { SL.looked++; L.ret = c3(SP.cc[0][ch], SP.cc[1][ch], SP.cc[2][ch]); L.mode = WM_RET; return; }
+            SL.missed++;
+            SL.state = 2;                                       // it drew: from here on the generator is not where pass A assumed it
         }
         L.o = f.info.ip + n * 1e-6;
         L.d = reflected;

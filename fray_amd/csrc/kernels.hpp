@@ -265,25 +265,44 @@ static __constant__ double kAAOffsets[5][2] = {{0, 0}, {0.6, 0}, {0.3, 0.3}, {0,
 static __device__ unsigned long long g_tileStat[65536][8];   // + rounds, cheap-step iterations, lanes x rounds standing at a search, at a direct-light loop
 FD unsigned long long tile_now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; }
 #endif
-struct WhittedArgs { DScene S; DCamera C; DFrame F; int nItems; int s0, cn; float* rgb; float* rad; uint32_t* mtWork; const uint32_t* x397; DStats* st; DCursors* cur; };
-template <int ST>
+// Speculative glossy fans (MODE 1-3 of k_whitted).  Reflection::shade with glossiness < 1 at depth 0 (shading.cpp:172-204) traces numSamples rays one
+// after the other, and the generator makes them a chain: sample i's direction is drawn after whatever sample i - 1's raytrace() drew.  With persistent
+// waves that chain set the duration of the whole kernel (hw9/dragon.fray: 26 rounds of a search and a shadow ray per floor pixel, every round as slow as
+// the wave's slowest lane; 1 % of the tiles took 6-14 ms each and the chip stood 64 % empty behind them).  Where the scene's lights draw nothing (point
+// lights only) the rays under such a fan usually draw nothing either, and then the fan's directions can be drawn ahead:
+//   pass A (MODE 1)  every camera sample as usual; a lane that reaches its sample's first depth-0 glossy activation draws the fan's directions back to
+//                    back, as they would come if no child drew, files them (one entry per sample, one child per direction) and drops the sample
+//   pass B (MODE 2)  every child is a raytrace() of its own (depth 1) on a generator that only records whether it was used; result + "drew nothing"
+//   pass C (MODE 3)  the filed samples again from their seeds -- the same draws, the same pushes -- except that the fan's children are looked up while
+//                    they drew nothing; the first child that did draw is traced in place and so is everything after it, with the true generator state
+// Colours are added in the reference's order in pass C, by the same code; a child's colour does not depend on who traced it.  The counting variants
+// (flag bit 0) run MODE 0: their counters are the reference's call counts, and a re-run sample would count its camera ray twice.
+static __global__ void k_add4(const int* __restrict__ a, int* __restrict__ sum) { if (threadIdx.x < 4) sum[threadIdx.x] += a[threadIdx.x]; }
+struct WhittedArgs { DScene S; DCamera C; DFrame F; int nItems; int s0, cn; float* rgb; float* rad; uint32_t* mtWork; const uint32_t* x397; DStats* st; DCursors* cur; SpecBuf sp; };
+template <int ST, int MODE>
 static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(WhittedArgs A)
 {
     Cnt c = zero_cnt();
     MtLong tab;
     tab.stride = gridDim.x * blockDim.x;
     tab.st = A.mtWork + (blockIdx.x * blockDim.x + threadIdx.x);
+    MtSpy spy;
+    spy.x = 0; spy.used = false;
     // A work item is one camera sample: (pixel item, sample s0 + k), k-major, so that the 64 lanes of a wave hold the SAME sample of an 8x8 pixel
     // tile and a pixel's samples -- independent given their seeds -- spread over the chip instead of queueing up in one lane (bokeh.fray,
     // 640x480 with 45 lens samples: 4 800 tiles of 45 samples each for 3 072 waves left the chip 22 % occupied).  The per-pixel sum in
     // sample order is k_pt_resolve's, as for the other integrators; a frame with one sample per pixel writes its pixel itself.
-    const int nItems = A.nItems, nTot = A.nItems * A.cn;
+    // Pass B's items are the filed children, pass C's the filed samples (their numbers are on the device: no host round trip between the passes).
+    const int nItems = A.nItems;
+    const int nTot = MODE == 2 ? A.sp.counters[1] : MODE == 3 ? A.sp.counters[0] : A.nItems * A.cn;
     DCursors* const cur = A.cur;
     DStats* const st = A.st;
     const uint32_t lane = threadIdx.x & 63u;
     __shared__ double rightRay[6][256];
     WhittedLane L;
     L.mode = WM_NEXT_PIXEL; L.sp = 0;
+    SpecLane SL;
+    SL.state = 2; SL.sp = 0; SL.base = 0; SL.looked = 0; SL.missed = 0;
     // the lane's pixel and camera sample
     int item = 0, x = 0, y = 0, k = 0, eye = 0;
     C3 cl = c3(0, 0, 0);
@@ -304,17 +323,24 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
         const DScene& S = KARG(WhittedArgs, AP, S);
         const DCamera& C = KARG(WhittedArgs, AP, C);
         const DFrame& F = KARG(WhittedArgs, AP, F);
+        const SpecBuf& SP = KARG(WhittedArgs, AP, sp);
         const bool stereo = C.stereoSeparation > 0;
         // ---- cheap steps, until every lane stands at a search, a direct-light loop, or has nothing left
         for (;;) {
             // Lanes that want a pixel wait until FRAY_WHITTED_REFILL of them do (or nobody has anything else to do): a wave keeps working on
             // neighbouring pixels -- its rays walk the same parts of the KD-trees -- instead of filling every free lane at once with pixels from elsewhere
+            if (MODE == 2 && spy.used && L.mode < WM_NEXT_SAMPLE) {           // this child drew: pass C will trace it in place
+                SP.cok[item] = 0;
+                spy.used = false;
+                L.sp = 0;
+                L.mode = WM_NEXT_PIXEL;
+            }
             const unsigned long long need = __ballot(L.mode == WM_NEXT_PIXEL);
             const unsigned long long busy = __ballot(L.mode != WM_NEXT_PIXEL && L.mode != WM_EXHAUSTED);
             const bool refill = need && ((int)__popcll(need) >= FRAY_WHITTED_REFILL || !busy);
             // a lane's generator is about to leave its 227-word register window: every lane of the wave that is inside a camera sample makes its
             // full state now, together (MtLong::materialise)
-            if (__any(L.mode < WM_NEXT_SAMPLE && tab.idx < 0 && tab.r.j >= FRAY_MT_EARLY)) {
+            if (MODE != 2 && __any(L.mode < WM_NEXT_SAMPLE && tab.idx < 0 && tab.r.j >= FRAY_MT_EARLY)) {
                 if (L.mode < WM_NEXT_SAMPLE && tab.idx < 0) tab.materialise();
             }
             const bool cheap = L.mode == WM_NEXT_PIXEL ? refill : (L.mode == WM_ROOT_RET || L.mode == WM_NEXT_SAMPLE || (L.mode < WM_ROOT_RET && wl_cheap(S, L)));
@@ -322,31 +348,18 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
 #ifdef FRAY_TILESTAT
             tsCheap++;
 #endif
-            // work items for the lanes that need a pixel: from the wave's pool, refilled one 8x8 tile at a time
+            // work items for the lanes that need one: from the wave's pool, refilled one tile of 64 at a time
             if (refill) {
                 if (poolNext == poolEnd && claimR < 8) {
-#ifdef FRAY_STAMPS
-                    {   // diagnostic: how long did the tile this wave just finished take?  stamp[15] = the longest, stamp[14] = tiles over 1 ms (2.4 M cycles)
-                        static __shared__ unsigned long long tileT0[4];
-                        unsigned long long t;
-                        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-                        const int w = threadIdx.x >> 6;
-                        if (lane == 0) {
-                            if (poolEnd != 0) { const unsigned long long dur = t - tileT0[w]; atomicMax(&st->stamp[15], dur); if (dur > 2400000ull) atomicAdd(&st->stamp[14], 1ull); if (dur > 12000000ull) atomicAdd(&st->stamp[13], 1ull); }
-                            tileT0[w] = t;
-                        }
-                    }
-#endif
-                    const int first = claim_items(cur, nTot, claimR);         // this lane's item of the claimed tile; nTot on every lane when nothing is left
-                    const int base = __builtin_amdgcn_readfirstlane(first - (int)lane);
-                    if (base < nTot) { poolNext = base; poolEnd = base + 64; }
+                    const int tile = claim_tile(cur, (nTot + 63) >> 6, claimR);
+                    if (tile >= 0) { poolNext = tile * 64; poolEnd = poolNext + 64 < nTot ? poolNext + 64 : nTot; }
 #ifdef FRAY_TILESTAT
                     {
                         const unsigned long long t = tile_now();
                         if (lane == 0) {
                             if (tsTile >= 0 && tsTile < 65536) { g_tileStat[tsTile][1] = t; g_tileStat[tsTile][4] = tsRounds; g_tileStat[tsTile][5] = tsCheap; g_tileStat[tsTile][6] = tsTrace; g_tileStat[tsTile][7] = tsDirect; }
                             tsRounds = tsCheap = tsTrace = tsDirect = 0;
-                            tsTile = base < nTot ? base / 64 : -1;
+                            tsTile = tile;
                             if (tsTile >= 0 && tsTile < 65536) { g_tileStat[tsTile][0] = t; g_tileStat[tsTile][2] = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; g_tileStat[tsTile][3] = tsKernel; }
                         }
                     }
@@ -356,11 +369,17 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
                 const int rank = (int)__popcll(need & ((1ull << lane) - 1ull));
                 if (L.mode == WM_NEXT_PIXEL) {
                     if (rank < have) {
-                        const int slot = poolNext + rank;
-                        k = slot / nItems;                                     // wave-uniform: nItems is a multiple of 64
-                        item = slot - k * nItems;
-                        if (item_pixel(F, item, x, y)) L.mode = WM_NEXT_SAMPLE;
-                        // a slot of a ragged edge bucket outside the frame: nothing to render, ask again
+                        int slot = poolNext + rank;
+                        if (MODE == 2) {
+                            item = slot;                                       // the child
+                            L.mode = WM_NEXT_SAMPLE;
+                        } else {
+                            if (MODE == 3) { SL.base = SP.eChildBase[slot]; slot = SP.eSlot[slot]; }
+                            k = slot / nItems;                                 // wave-uniform in passes 0 and A: nItems is a multiple of 64
+                            item = slot - k * nItems;
+                            if (item_pixel(F, item, x, y)) L.mode = WM_NEXT_SAMPLE;
+                            // a slot of a ragged edge bucket outside the frame: nothing to render, ask again
+                        }
                     } else if (have == 0 && claimR >= 8) {
                         L.mode = WM_EXHAUSTED;
                     }
@@ -369,7 +388,12 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
                 poolNext += want < have ? want : have;
             }
             if (L.mode == WM_NEXT_SAMPLE) {
-                {
+                if (MODE == 2) {                                              // a filed child: raytrace(ray) at depth 1
+                    const int e = SP.cEntry[item];
+                    wl_start(L, v3(SP.eo[0][e], SP.eo[1][e], SP.eo[2][e]), v3(SP.cd[0][item], SP.cd[1][item], SP.cd[2][item]));
+                    L.depth = 1;
+                    spy.used = false;
+                } else {
                     const int i = KARG(WhittedArgs, AP, s0) + k;
                     const uint32_t* const x397 = KARG(WhittedArgs, AP, x397);
                     const uint32_t p = (uint32_t)y * (uint32_t)F.W + (uint32_t)x;
@@ -394,9 +418,15 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
                     }
                     eye = 0;
                     wl_start(L, o, d);
+                    SL.state = (MODE == 1 || MODE == 3) && !stereo ? 0 : 2;
                 }
-            } else if (L.mode == WM_ROOT_RET) {                              // the camera ray's raytrace() returned
-                if (stereo && eye == 0) {
+            } else if (L.mode == WM_ROOT_RET) {                              // the camera ray's (pass B: the child's) raytrace() returned
+                if (MODE == 2) {
+                    SP.cc[0][item] = L.ret.r; SP.cc[1][item] = L.ret.g; SP.cc[2][item] = L.ret.b;
+                    SP.cok[item] = spy.used ? 0 : 1;
+                    spy.used = false;
+                    L.mode = WM_NEXT_PIXEL;
+                } else if (stereo && eye == 0) {
                     cl = L.ret;
                     eye = 1;
                     wl_start(L, v3(rightRay[0][threadIdx.x], rightRay[1][threadIdx.x], rightRay[2][threadIdx.x]),
@@ -426,23 +456,75 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
                     L.mode = WM_NEXT_PIXEL;
                 }
             } else if (L.mode < WM_ROOT_RET && wl_cheap(S, L)) {
-                wl_cheap_step<ST, MtLong>(S, L, tab, c, ovf);
+                if (MODE == 2) wl_cheap_step<ST, MtSpy, 0>(S, L, spy, c, ovf, SP, SL);
+                else wl_cheap_step<ST, MtLong, MODE>(S, L, tab, c, ovf, SP, SL);
             }
         }
         STAMP(12);
         if (!__any(L.mode != WM_EXHAUSTED)) break;
+        if (MODE == 1) {
+            // ---- pass A: the lanes standing at a fan to file (WM_DEFER).  One pair of atomics per wave: entries by rank, children by prefix sum.
+            const bool def = L.mode == WM_DEFER;
+            const unsigned long long dm = __ballot(def);
+            if (dm) {
+                const int cnt = def ? L.stack[L.sp - 1].count : 0;
+                int incl = cnt;
+#pragma unroll
+                for (int dlt = 1; dlt < 64; dlt <<= 1) { const int t = __shfl_up(incl, dlt); if ((int)lane >= dlt) incl += t; }
+                const int total = __builtin_amdgcn_readlane(incl, 63);
+                int e0 = 0, c0 = 0;
+                if (lane == 0) { e0 = atomicAdd(&SP.counters[0], (int)__popcll(dm)); c0 = atomicAdd(&SP.counters[1], total); }
+                e0 = __builtin_amdgcn_readfirstlane(e0); c0 = __builtin_amdgcn_readfirstlane(c0);
+                if (def) {
+                    const WFrame& f = L.stack[L.sp - 1];
+                    const FRAY_RO DShader& sh = S.shaders[f.shader];
+                    const int e = e0 + (int)__popcll(dm & ((1ull << lane) - 1ull)), cb = c0 + incl - cnt;
+                    SP.eSlot[e] = k * nItems + item; SP.eChildBase[e] = cb;
+                    const V3 n = faceforward(f.d, f.info.norm);
+                    const V3 org = f.info.ip + n * 1e-6;
+                    SP.eo[0][e] = org.x; SP.eo[1][e] = org.y; SP.eo[2][e] = org.z;
+                    V3 bb, cc;
+                    orthonormalSystem(n, bb, cc);
+                    for (int q = 0; q < cnt; q++) {                           // the draws of shading.cpp:172-204, with nothing drawn in between
+                        V3 reflected;
+                        for (;;) {
+                            double dx, dy;
+                            rng_unit_disc(tab, dx, dy);
+                            dx *= sh.deflectionScaling;
+                            dy *= sh.deflectionScaling;
+                            const V3 nn = normalized(n + bb * dx + cc * dy);
+                            reflected = reflect(f.d, nn);
+                            if (dot(reflected, n) > 0) break;
+                        }
+                        SP.cEntry[cb + q] = e;
+                        SP.cd[0][cb + q] = reflected.x; SP.cd[1][cb + q] = reflected.y; SP.cd[2][cb + q] = reflected.z;
+                    }
+                    L.sp = 0;
+                    L.mode = WM_NEXT_PIXEL;                                   // pass C renders this sample
+                }
+            }
+        }
 #ifdef FRAY_TILESTAT
         tsRounds++; tsTrace += __popcll(__ballot(L.mode == WM_TRACE)); tsDirect += __popcll(__ballot(L.mode == WM_SHADE));
 #endif
         if (L.mode == WM_TRACE) wl_trace_step<ST>(S, L, c);
         STAMP(14);
-        if (L.mode == WM_SHADE && S.shaders[L.shader].kind <= 2) wl_direct_step<ST, MtLong>(S, L, tab, c);
+        if (L.mode == WM_SHADE && S.shaders[L.shader].kind <= 2) {
+            if (MODE == 2) wl_direct_step<ST, MtSpy>(S, L, spy, c);
+            else wl_direct_step<ST, MtLong>(S, L, tab, c);
+        }
         STAMP(10);
     }
 #ifdef FRAY_STAMPS
     if (lane < 16) atomicAdd(&st->stamp[lane], g_stampAcc[threadIdx.x >> 6][lane]);
 #endif
-    if (ovf) atomicAdd(&st->rngOverflow, 1ull);
+    if (MODE == 3) {                                                        // how the speculation went (frayhip_scene_get_option)
+        int a = SL.looked, b = SL.missed;
+#pragma unroll
+        for (int dlt = 32; dlt > 0; dlt >>= 1) { a += __shfl_down(a, dlt); b += __shfl_down(b, dlt); }
+        if (lane == 0 && (a | b)) { atomicAdd(&A.sp.counters[2], a); atomicAdd(&A.sp.counters[3], b); }
+    }
+    if (ovf && MODE != 2) atomicAdd(&st->rngOverflow, 1ull);
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }

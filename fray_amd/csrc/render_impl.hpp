@@ -82,6 +82,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     DCursors* cursors = (DCursors*)((unsigned char*)sc->d_stats + kCursorOffset);
     HIP_TRY(hipEventRecord(sc->evA, stream));
     size_t nTraceEvents = 0, nShadowEvents = 0;
+    const int* fanTotals = nullptr;          // device: the speculative fans' counters summed over the frame's batches
 
     if (f->mode == FRAYHIP_MODE_PRIMARY_ID) {
         if (nItems > 0) {
@@ -104,37 +105,71 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 auto r256 = [](size_t b) { return (b + 255) / 256 * 256; };
                 const int grid = persistent_grid((size_t)nItems * spp, whitted_waves(ST));
                 const size_t colBytes = r256((size_t)grid * 256 * 624 * sizeof(uint32_t));
+                // Speculative glossy fans (dev_whitted.hpp): three passes per batch, with room for one filed entry per camera sample and specFanMax children each.
+                // Not in the counting variants (their counters are the reference's call counts), not in stereo frames (the right eye continues the left eye's generator).
+                const int fan = (!(ST & 1) && sc->speculateFans && !(sc->camera.stereoSeparation > 0)) ? sc->specFanMax : 0;
+                const size_t perSample = 16 + (fan > 0 ? 32 + (size_t)fan * 41 : 0);
                 int chunk = 0;
                 for (;;) {          // planned again with half the budget when the allocation fails (ensure_work_or_shrink)
                     const size_t wb = work_budget(sc);
                     const size_t budget = wb > colBytes + (64u << 20) ? wb - colBytes : (64u << 20);
-                    chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / ((size_t)nItems * 16));
+                    chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / ((size_t)nItems * perSample));
                     if (chunk > spp) chunk = spp;
-                    while (chunk > 1 && (size_t)nItems * chunk >= ((size_t)1 << 31)) chunk /= 2;
-                    const size_t slots = (size_t)nItems * chunk;
-                    const int rc = ensure_work_or_shrink(sc, colBytes + r256((size_t)nItems * 12) + r256(slots * 12) + r256(slots * 4));
+                    while (chunk > 1 && (size_t)nItems * chunk * (size_t)std::max(fan, 1) >= ((size_t)1 << 31)) chunk /= 2;
+                    const size_t slots = (size_t)nItems * chunk, kids = slots * (size_t)fan;
+                    const int rc = ensure_work_or_shrink(sc, colBytes + r256((size_t)nItems * 12) + r256(slots * 12) + r256(slots * 4) +
+                                                             (fan > 0 ? 256 + 2 * r256(slots * 4) + 3 * r256(slots * 8) + r256(kids * 4) + 3 * r256(kids * 8) + 3 * r256(kids * 4) + r256(kids) : 0));
                     if (rc == FRAYHIP_RETRY_SMALLER && f->spp_chunk <= 0 && chunk > 1) continue;
                     if (rc) { if (rc == FRAYHIP_RETRY_SMALLER) return FRAYHIP_E_NOMEM; return rc; }
                     break;
                 }
+                if (fan > 0 && (size_t)nItems * chunk * (size_t)fan >= ((size_t)1 << 31)) { set_error("frayhip_render: a glossy fan of this size does not fit one batch of this frame (set speculate_fans to 0)"); return FRAYHIP_E_UNSUPPORTED; }
                 unsigned char* p = (unsigned char*)sc->d_work;
                 auto take = [&](size_t b) { unsigned char* r = p; p += r256(b); return r; };
                 uint32_t* mtWork = (uint32_t*)take(colBytes);
                 float* sum = (float*)take((size_t)nItems * 12);
                 float* rad = (float*)take((size_t)nItems * chunk * 12);
                 uint32_t* x397 = (uint32_t*)take((size_t)nItems * chunk * 4);
+                SpecBuf SPB{};
+                if (fan > 0) {
+                    const size_t slots = (size_t)nItems * chunk, kids = slots * (size_t)fan;
+                    SPB.counters = (int*)take(256);
+                    SPB.minCount = 8;
+                    SPB.eSlot = (int*)take(slots * 4); SPB.eChildBase = (int*)take(slots * 4);
+                    for (int q = 0; q < 3; q++) SPB.eo[q] = (double*)take(slots * 8);
+                    SPB.cEntry = (int*)take(kids * 4);
+                    for (int q = 0; q < 3; q++) SPB.cd[q] = (double*)take(kids * 8);
+                    for (int q = 0; q < 3; q++) SPB.cc[q] = (float*)take(kids * 4);
+                    SPB.cok = take(kids);
+                }
                 for (int s0 = 0; s0 < spp; s0 += chunk) {
                     const int cn = std::min(chunk, spp - s0);
-                    if (s0 > 0) HIP_TRY(hipMemsetAsync(cursors, 0, sizeof(DCursors), stream));      // the tile cursors of the previous batch
+                    if (s0 > 0) HIP_TRY(hipMemsetAsync(cursors, 0, 3 * sizeof(DCursors), stream));  // the tile cursors of the previous batch
+                    if (fan > 0) HIP_TRY(hipMemsetAsync(SPB.counters, 0, s0 == 0 ? 256 : 32, stream));
                     hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * cn + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
                     hipEvent_t a = pool_event(sc->evPool, nTraceEvents), b = pool_event(sc->evPool, nTraceEvents + 1);
                     if (!a || !b) return FRAYHIP_E_NOMEM;
                     HIP_TRY(hipEventRecord(a, stream));
-                    hipLaunchKernelGGL(k_whitted<ST>, dim3(grid), dim3(256), 0, stream, WhittedArgs{S, C, F, nItems, s0, cn, d_rgb, rad, mtWork, x397, sc->d_stats, cursors});
+                    const WhittedArgs WA{S, C, F, nItems, s0, cn, d_rgb, rad, mtWork, x397, sc->d_stats, cursors, SPB};
+                    if constexpr (!(ST & 1)) {
+                        if (fan > 0) {
+                            WhittedArgs WB = WA, WC = WA;
+                            WB.cur = cursors + 1; WC.cur = cursors + 2;
+                            hipLaunchKernelGGL((k_whitted<ST, 1>), dim3(grid), dim3(256), 0, stream, WA);     // samples; fans are filed
+                            hipLaunchKernelGGL((k_whitted<ST, 2>), dim3(grid), dim3(256), 0, stream, WB);     // the fans' children
+                            hipLaunchKernelGGL((k_whitted<ST, 3>), dim3(grid), dim3(256), 0, stream, WC);     // the filed samples, children looked up
+                        } else {
+                            hipLaunchKernelGGL((k_whitted<ST, 0>), dim3(grid), dim3(256), 0, stream, WA);
+                        }
+                    } else {
+                        hipLaunchKernelGGL((k_whitted<ST, 0>), dim3(grid), dim3(256), 0, stream, WA);
+                    }
                     HIP_TRY(hipEventRecord(b, stream));
                     nTraceEvents += 2;
                     if (spp > 1) hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, stream, F, C, set.saturation, nItems, s0, cn, rad, (const float*)nullptr, sum, d_rgb);
+                    if (fan > 0) hipLaunchKernelGGL(k_add4, dim3(1), dim3(64), 0, stream, SPB.counters, SPB.counters + 8);       // the frame's totals over its batches
                 }
+                fanTotals = fan > 0 ? SPB.counters + 8 : nullptr;
             } else if (nItems > 0) {
                 // Wavefront Whitted (no recursive shader in the scene): batches of `chunk` samples per pixel through
                 // k_wh_shade -> k_wh_visible -> k_wh_gather, then the ordered per-pixel sum (k_pt_resolve).
@@ -185,10 +220,10 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     if (!ea || !eb || !ec || !ed) return FRAYHIP_E_NOMEM;
                     HIP_TRY(hipEventRecord(ea, stream));
                     if (s0 > 0) HIP_TRY(hipMemsetAsync(cursors, 0, 2 * sizeof(DCursors), stream));        // the previous batch's tile cursors (one set per kernel)
-                    // tiles are claimed when a wave gets at least 32 of them, walked with a fixed stride otherwise (next_tile, kernels.hpp)
-                    const bool claimShade = bs / 64 >= (size_t)grid * 4 * 32;
+                    // tiles are claimed when a wave gets at least 16 of them, walked with a fixed stride otherwise (next_tile, kernels.hpp)
+                    const bool claimShade = bs / 64 >= (size_t)grid * 4 * 16;
                     const int gridVis = persistent_grid(bN * (size_t)T, anyhit_waves(ST));
-                    const bool claimVis = (bN * (size_t)T) / 64 >= (size_t)gridVis * 4 * 32;
+                    const bool claimVis = (bN * (size_t)T) / 64 >= (size_t)gridVis * 4 * 16;
                     hipLaunchKernelGGL(k_wh_shade<ST>, dim3(grid), dim3(256), 0, stream, WhShadeArgs{S, C, F, nItems, s0, cn, Q, mtWork, x397, sc->d_stats, claimShade ? cursors : nullptr});
                     HIP_TRY(hipEventRecord(eb, stream));
                     nTraceEvents += 2;
@@ -343,6 +378,11 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     drain.armed = false;                    // every lane was joined into `stream` above
     DStats dsv[2];
     HIP_TRY(hipMemcpy(dsv, sc->d_stats, sizeof dsv, hipMemcpyDeviceToHost));
+    {
+        int ft[4] = {0, 0, 0, 0};
+        if (fanTotals) HIP_TRY(hipMemcpy(ft, fanTotals, sizeof ft, hipMemcpyDeviceToHost));
+        for (int q = 0; q < 4; q++) sc->lastFans[q] = ft[q];
+    }
 #ifdef FRAY_LEAFSTAT
     {
         unsigned long long ls[4] = {0, 0, 0, 0}, zero[4] = {0, 0, 0, 0};

@@ -47,6 +47,9 @@ struct frayhip_scene {
     frayhip_camera camera{};
     frayhip_settings settings{};
     bool whittedNeedsRecursion = false;
+    int specFanMax = 0;               // > 0: the largest numSamples of a glossy Refl shader, in a scene whose lights draw no random numbers (speculative glossy fans, dev_whitted.hpp)
+    bool speculateFans = true;        // option "speculate_fans"
+    long long lastFans[4] = {0, 0, 0, 0};   // the last frame's fans filed, children traced ahead, children looked up, fans given up part of the way (frayhip_scene_get_option)
     int lightSampleCount = 0;         // sum over lights of Light::getNumSamples(): segments a Lambert / Phong hit queues (wavefront Whitted)
     bool extGeometry = false;         // Cube / CSG nodes present
     bool textured = false;            // textures or a loaded environment map present: selects the <ST | 8> variants when neither bit 1 nor bit 2 is set
@@ -74,7 +77,7 @@ namespace frayhip_detail {
 
 // d_stats: two DStats blocks, then (256-byte aligned) the work cursors; one memset clears all of it per frame
 constexpr size_t kCursorOffset = (2 * sizeof(DStats) + 255) / 256 * 256;
-constexpr size_t kStatsBytes = kCursorOffset + 2 * sizeof(DCursors);     // two sets of tile cursors: a batch's closest-hit and any-hit kernels
+constexpr size_t kStatsBytes = kCursorOffset + 3 * sizeof(DCursors);     // sets of tile cursors: a batch's closest-hit and any-hit kernels; the three passes of speculative Whitted
 
 DCamera camera_begin_frame(const frayhip_camera& c, int W, int H);
 int persistent_grid(size_t n, int wavesPerSimd);

@@ -111,10 +111,17 @@ class Scene:
             self._dev = C.c_void_p()
 
     def set_option(self, name, value):
-        """frayhip_scene_set_option: "pt_lanes" (1..4 batches in flight), "pt_budget_mib" (queue memory)."""
+        """frayhip_scene_set_option: "pt_lanes" (1..4 batches in flight), "pt_budget_mib" (queue memory), "speculate_fans" (0 / 1)."""
         self._need_dev()
         _check(lib.frayhip_scene_set_option(self._dev, name.encode(), int(value)))
         return self
+
+    def get_option(self, name):
+        """frayhip_scene_get_option: an option's value, or a figure of the last frame ("fans_filed", "fan_children", "fan_children_looked_up", "fans_given_up")."""
+        self._need_dev()
+        v = C.c_int64(0)
+        _check(lib.frayhip_scene_get_option(self._dev, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def _frame(self, mode, seed, bucket_first, bucket_stride, spp_chunk, stats):
         return abi.Frame(mode=mode, seed=seed, bucket_first=bucket_first, bucket_stride=bucket_stride,

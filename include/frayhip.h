@@ -282,8 +282,16 @@ int  frayhip_scene_set_view(frayhip_scene* s, const frayhip_camera* camera, cons
  *                          1 serialises every launch, which is what a per-kernel profile wants)
  *   "pt_budget_mib" MiB of device memory a path-traced frame may use for its queues (about 340 B per path in
  *                          flight; default 24576): a frame is cut into batches of samples that fit
- * The environment variables FRAYHIP_PT_LANES / FRAYHIP_PT_BUDGET_MIB preset them at frayhip_scene_create. */
+ *   "speculate_fans" 0 / 1  glossy reflections of eight or more samples at depth 0 (Reflection::shade, shading.cpp:172-204) in a scene
+ *                          whose lights draw no random numbers: the fan's directions are drawn ahead and its rays traced as work items of
+ *                          their own, then looked up while none of them drew (default 1; the picture is the same either way,
+ *                          hw9/dragon.fray 1080p 16.4 -> 7.8 ms)
+ * The environment variables FRAYHIP_PT_LANES / FRAYHIP_PT_BUDGET_MIB / FRAYHIP_SPECULATE_FANS preset them at frayhip_scene_create. */
 int  frayhip_scene_set_option(frayhip_scene* s, const char* name, int64_t value);
+/* Reads an option back, or one of the last frame's read-only figures: "fans_filed" (camera samples whose first fan was drawn ahead),
+ * "fan_children" (rays traced ahead), "fan_children_looked_up" (results used), "fans_given_up" (fans in which a ray drew a random
+ * number after all, so that the rest of the fan was traced in place). */
+int  frayhip_scene_get_option(frayhip_scene* s, const char* name, int64_t* value);
 
 /* Threads: a frayhip_scene renders one frame at a time (it owns one workspace and one set of
  * counters), as the reference calls render() from one thread at a time (main.cpp:407-412,448);

@@ -59,12 +59,14 @@ def write_bmp(path, rgb):
         f.write(data)
 
 
-def random_scene(rng, tmp, gi, flavour=0, bump_on=("ball", "blob", "box")):
+def random_scene(rng, tmp, gi, flavour=0, bump_on=("ball", "blob", "box"), fans=False):
     """flavour 0: every geometry kind (the Cube / CSG kernel variants); 1: no Cube / CSG (the KD variants); 2: no Cube / CSG and no mesh big
     enough for a KD-tree (the lean variants, with textures).
     bump_on: the geometries that may get a bump map.  Only Mesh::intersectTriangle writes info.dNdx / dNdy (mesh.cpp:135-136); a bump map on a Sphere
     or a Cube makes the reference read an uninitialised IntersectionInfo (geometry.h:33-39, Vector() {} -- shading.cpp:416), so comparisons with the
-    reference's object code (tests/test_oracle_vs_ref_fuzz.py) pass ("blob",); the product and the oracle define those vectors as zero."""
+    reference's object code (tests/test_oracle_vs_ref_fuzz.py) pass ("blob",); the product and the oracle define those vectors as zero.
+    fans: point lights only, glossy reflections of 8-13 samples, a glossy floor -- the scenes the renderer's speculative glossy fans apply to
+    (fray_amd/csrc/dev_whitted.hpp); the other scenes all hold a RectLight, whose samples draw random numbers, and never take that path."""
     W, H = int(rng.integers(40, 90)), int(rng.integers(30, 70))
     s = ["GlobalSettings {\n\tframeWidth %d\n\tframeHeight %d\n\tambientLight (0.15, 0.15, 0.2)\n\tmaxTraceDepth %d\n\twantAA %s\n\tgi %d\n\tpathsPerPixel %d\n}" %
          (W, H, int(rng.integers(2, 5)), "on" if (not gi and rng.random() < 0.3) else "off", gi, int(rng.choice([3, 9])))]   # 9 spp: four batches on four streams
@@ -74,7 +76,10 @@ def random_scene(rng, tmp, gi, flavour=0, bump_on=("ball", "blob", "box")):
         s[-1] = s[-1][:-2] + "\n\tdof on\n\tnumSamples %d\n\tfNumber %.1f\n\tfocalPlaneDist 14\n}" % (int(rng.integers(2, 5)), 2 + rng.random() * 6)
     if rng.random() < 0.25:
         s[-1] = s[-1][:-2] + "\n\tstereoSeparation %.2f\n}" % (0.1 + rng.random() * 0.3)
-    s.append("RectLight l1 {\n\ttranslate (%.2f, 12, %.2f)\n\tscale (5, 5, 5)\n\trotate (%.1f, 0, %.1f)\n\tpower 40\n\txSubd 2\n\tySubd 2\n}" % (rng.normal() * 2, rng.normal() * 2, rng.normal() * 10, rng.normal() * 10))
+    if fans:
+        s.append("PointLight l1 {\n\tpos (%.2f, 12, %.2f)\n\tpower 160\n}" % (rng.normal() * 2, rng.normal() * 2))
+    else:
+        s.append("RectLight l1 {\n\ttranslate (%.2f, 12, %.2f)\n\tscale (5, 5, 5)\n\trotate (%.1f, 0, %.1f)\n\tpower 40\n\txSubd 2\n\tySubd 2\n}" % (rng.normal() * 2, rng.normal() * 2, rng.normal() * 10, rng.normal() * 10))
     if rng.random() < 0.5:
         s.append("PointLight l2 {\n\tpos (%.2f, 9, -6)\n\tpower 60\n\tcolor (0.9, 0.8, 0.7)\n}" % (rng.normal() * 4))
     s.append("Plane floor {\n\ty -2\n\tlimit 40\n}")
@@ -104,11 +109,13 @@ def random_scene(rng, tmp, gi, flavour=0, bump_on=("ball", "blob", "box")):
     s.append("Lambert painted {\n\ttexture pic\n}")
     s.append("Fresnel fres {\n\tior 1.45\n}")
     s.append("Layered wet {\n\tlayer painted (1, 1, 1)\n\tlayer mir (1, 1, 1) fres\n}")
-    s.append("Refl rough {\n\tglossiness %.2f\n\tnumSamples 3\n\tmultiplier 0.8\n}" % (0.75 + rng.random() * 0.2))
+    s.append("Refl rough {\n\tglossiness %.2f\n\tnumSamples %d\n\tmultiplier 0.8\n}" % (0.75 + rng.random() * 0.2, int(rng.integers(8, 14)) if fans else 3))
+    if fans:
+        s.append("Layered sheen {\n\tlayer lam (1, 1, 1)\n\tlayer rough (0.3, 0.3, 0.35)\n}")
     s.append("Const flat {\n\tcolor (0.2, 0.9, 0.4)\n}")
     shaders = ["lam", "grey", "ph", "mir", "glass", "coat", "painted", "wet", "rough", "flat"] if not gi else ["lam", "grey", "mir", "glass", "painted"]
     geoms = ["ball", "box", "carved", "lens", "blob", "shard", "both", "deep"] if flavour == 0 else ["ball", "blob", "shard", "blob", "ball", "shard", "blob", "blob"]
-    s.append("Node floorNode {\n\tgeometry floor\n\tshader lam\n}")
+    s.append("Node floorNode {\n\tgeometry floor\n\tshader %s\n}" % ("sheen" if fans else "lam"))
     for i, g in enumerate(geoms):
         sh = shaders[int(rng.integers(len(shaders)))]
         sc = 0.6 + rng.random() * 1.2
@@ -177,6 +184,52 @@ def test_random_scene_parity_other_kernel_variants(fray, abi, oracle, gpu, tmp_p
         ref, _ = oracle.render(s.desc, abi.MODE_RENDER, seed=seed)
         assert np.array_equal(img, img2), g
         assert np.all(np.abs(img.astype(np.float64) - ref) <= 1e-5 * np.maximum(1.0, np.abs(ref))), g
+    s.close()
+
+
+@pytest.mark.parametrize("seed", range(200, 212))
+def test_random_scene_speculative_fans(fray, abi, oracle, gpu, tmp_path, seed):
+    """Scenes the speculative glossy fans apply to (point lights only, fans of 8-13 samples on the floor and on objects), all three kernel families.
+    The fans' children that reach another glossy surface, a mirror or glass and draw below them make the speculation fail part of the way through a
+    fan; the picture must be the one rendered without speculation (option speculate_fans 0; the counting variant never speculates) and the oracle's."""
+    rng = np.random.default_rng(1000 + seed)
+    s = fray.Scene.parseScene(random_scene(rng, tmp_path, 0, flavour=seed % 3, fans=True))
+    s.camera.stereoSeparation = 0.0                      # stereo frames do not speculate
+    s.beginRender()
+    img, _ = s.render(seed=seed)
+    img2, _ = s.render(seed=seed, stats=True)
+    s.set_option("speculate_fans", 0)
+    img3, _ = s.render(seed=seed)
+    s.set_option("speculate_fans", 1)
+    img4, _ = s.render(seed=seed)
+    ref, _ = oracle.render(s.desc, abi.MODE_RENDER, seed=seed)
+    assert np.all(np.isfinite(img))
+    filed, kids, looked = (s.get_option(k) for k in ("fans_filed", "fan_children", "fan_children_looked_up"))
+    assert filed > 0 and kids >= 8 * filed and 0 < looked <= kids, (filed, kids, looked)      # the last frame did speculate, and used what it traced ahead
+    assert np.array_equal(img, img3) and np.array_equal(img, img2) and np.array_equal(img, img4)
+    assert np.all(np.abs(img.astype(np.float64) - ref) <= 1e-5 * np.maximum(1.0, np.abs(ref)))
+    s.close()
+
+
+def test_glossy_fans_scene(fray, abi, oracle, gpu):
+    """tests/scenes/glossy_fans: fans whose children hit the sky and diffuse objects (looked up), a second glossy wall, a mirror ball, a box coated with
+    two glossy layers (children that draw: traced in place), with anti-aliasing (five samples per pixel: the filed samples of a batch)."""
+    s = fray.Scene.parseScene(os.path.join(os.path.dirname(__file__), "scenes", "glossy_fans", "scene.fray"))
+    for aa in (0, 1):
+        s.settings.wantAA = aa
+        s.beginRender()
+        img, _ = s.render(seed=7)
+        filed, kids, looked, given_up = (s.get_option(k) for k in ("fans_filed", "fan_children", "fan_children_looked_up", "fans_given_up"))
+        assert filed > 1000 and looked > 0 and given_up > 0 and looked < kids, (filed, kids, looked, given_up)      # both outcomes occur in this scene
+        img2, _ = s.render(seed=7, stats=True)
+        assert s.get_option("fans_filed") == 0                 # the counting variant does not speculate
+        s.set_option("speculate_fans", 0)
+        img3, _ = s.render(seed=7)
+        assert s.get_option("fans_filed") == 0
+        assert np.array_equal(img, img3) and np.array_equal(img, img2), aa
+        if aa == 0:
+            ref, _ = oracle.render(s.desc, abi.MODE_RENDER, seed=7)
+            assert np.all(np.abs(img.astype(np.float64) - ref) <= 1e-5 * np.maximum(1.0, np.abs(ref)))
     s.close()
 
 

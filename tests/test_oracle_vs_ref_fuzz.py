@@ -65,3 +65,16 @@ def test_generated_scene_through_reference_object_code_and_oracle(fray, abi, ora
     for g in (gi, 1 - gi):
         z = ref_fixture(scene, "fz%d_%d" % (seed, g), W, H, "gi=%d" % g, tmp_path)
         compare(fray, abi, oracle, z, scene, g)
+
+
+@pytest.mark.parametrize("seed", (3200, 3201, 3202))
+def test_generated_glossy_fan_scene_through_reference_object_code_and_oracle(fray, abi, oracle, tmp_path, seed):
+    """The scenes the device's speculative glossy fans apply to (point lights only, fans of 8-13 samples: tests/test_fuzz_parity.py): here the oracle they
+    are compared with is itself compared with the reference's object code."""
+    rng = np.random.default_rng(seed)
+    scene = random_scene(rng, pathlib.Path(tmp_path), 0, flavour=seed % 3, bump_on=("blob",), fans=True)
+    s = fray.Scene.parseScene(scene)
+    W, H = s.settings.frameWidth, s.settings.frameHeight
+    s.close()
+    z = ref_fixture(scene, "fans%d" % seed, W, H, "gi=0", tmp_path)
+    compare(fray, abi, oracle, z, scene, 0)

@@ -94,6 +94,11 @@ def main():
             for a, b in (("SQ_WAIT_ANY", "wave_wait_any_frac"), ("SQ_WAIT_INST_ANY", "wave_wait_inst_frac"), ("SQ_ACTIVE_INST_ANY", "wave_active_frac")):
                 if a in per:
                     d[b] = per[a] / per["SQ_WAVE_CYCLES"]
+        if per.get("SQ_WAVE_CYCLES") and simd_cycles:
+            # how full the chip was on average over the launch: SQ_WAVE_CYCLES counts resident waves in quad-cycles.  Against the kernel's waves per SIMD
+            # (tools/kernel_resources.py) this shows a launch's tail: round 4 found k_whitted at 0.7 of 2-3 (a few tiles set the duration) and the
+            # strided wavefront kernels at 3.1-3.3 of 4
+            d["mean_resident_waves_per_simd"] = per["SQ_WAVE_CYCLES"] * 4.0 / simd_cycles
         if per.get("SQ_WAVES") and "SQ_INSTS_VALU" in per:
             d["valu_insts_per_wave"] = per["SQ_INSTS_VALU"] / per["SQ_WAVES"]
         if "TCC_HIT_sum" in per and (per["TCC_HIT_sum"] + per.get("TCC_MISS_sum", 0)) > 0:
@@ -101,7 +106,7 @@ def main():
         d["formulas"] = ("valu_wave_active_per_simd_cycle = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) (quad-cycles; > 1 possible for 32-bit code); "
                          "valu_issue_xN = SQ_INSTS_VALU x N / SIMD cycles; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait fractions over SQ_WAVE_CYCLES; "
                          "ta_busy and the four stall fractions = *_sum / (GRBM_GUI_ACTIVE / 8 x 256 CUs); l1_reads_per_read_instruction = TCP_TOTAL_READ_sum / TA_FLAT_READ_WAVEFRONTS_sum, "
-                         "writes likewise (calibration: tools/ubench/l1_access.hip)")
+                         "writes likewise (calibration: tools/ubench/l1_access.hip); mean_resident_waves_per_simd = SQ_WAVE_CYCLES x 4 / SIMD cycles")
         rec["derived"] = d
         if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
             rec["hbm_bytes_per_launch"] = (per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024.0

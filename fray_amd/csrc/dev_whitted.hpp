@@ -44,6 +44,7 @@ struct SpecBuf {
     double* eo[3];                    //            the children's common origin
     int* cEntry; double* cd[3];       // per child: its entry, its direction
     float* cc[3]; unsigned char* cok; //            its colour; 1 = traced without a draw
+    unsigned char* cdraws;            //            how many unit-disc samples its direction took (pass C skips their words instead of redoing the trigonometry), 0 = more than 255
 };
 struct SpecLane { int state, sp, base, looked, missed; };      // 0 = armed, 1 = the fan on stack level sp is being looked up from child `base`, 2 = off until the next sample
 
@@ -133,6 +134,19 @@ FD void wl_cheap_step(const DScene& S, WhittedLane& L, G& tab, Cnt& c, bool& ove
             if (MODE == 3 && SL.state == 1 && SL.sp == L.sp - 1) SL.state = 2;
             L.ret = f.acc / (float)f.count; L.sp--; L.mode = WM_RET; return;
         }
+        if (MODE == 3 && SL.state == 1 && SL.sp == L.sp - 1) {  // the filed fan: this child's raytrace() ran in pass B, from the ray pass A drew for it, unless a draw came in between
+            const int ch = SL.base + f.i;
+            const int it = SP.cdraws[ch];
+            if (SP.cok[ch] && it) {
+                for (int q = 0; q < 4 * it; q++) (void)tab.next();  // the words of its unit-disc samples (two doubles each)
+                SL.looked++;
+                L.ret = c3(SP.cc[0][ch], SP.cc[1][ch], SP.cc[2][ch]);
+                L.mode = WM_RET;
+                return;
+            }
+            SL.missed++;
+            SL.state = 2;                                       // it drew: from here on the generator is not where pass A assumed it
+        }
         V3 n = faceforward(f.d, f.info.norm);
         V3 b, cc;
         orthonormalSystem(n, b, cc);
@@ -145,12 +159,6 @@ FD void wl_cheap_step(const DScene& S, WhittedLane& L, G& tab, Cnt& c, bool& ove
             V3 nn = normalized(n + b * x + cc * y);
             reflected = reflect(f.d, nn);
             if (dot(reflected, n) > 0) break;
-        }
-        if (MODE == 3 && SL.state == 1 && SL.sp == L.sp - 1) {  // the filed fan: this child's raytrace() ran in pass B, from this very ray, unless a draw came in between
-            const int ch = SL.base + f.i;
-            if (SP.cok[ch]) { SL.looked++; L.ret = c3(SP.cc[0][ch], SP.cc[1][ch], SP.cc[2][ch]); L.mode = WM_RET; return; }
-            SL.missed++;
-            SL.state = 2;                                       // it drew: from here on the generator is not where pass A assumed it
         }
         L.o = f.info.ip + n * 1e-6;
         L.d = reflected;

@@ -61,6 +61,10 @@ constexpr int waves_for(int st, int n) { return (st & 2) ? (FRAY_CSG_WAVES < n ?
 #define FRAY_WHITTED_WAVES_KD 2   // k_whitted beside KD meshes (and no Cube / CSG): 211 VGPR, nothing spilled; dragon Whitted 17.1 -> 16.4 ms against 3 waves (168 VGPR, 82 spilled),
 #endif                            // 1 wave: 18.0; the Cube / CSG variants (bokeh) measure the same at 2 and 3 and stay at 3
 constexpr int whitted_waves(int st) { return waves_for(st, (st & 6) == 4 ? FRAY_WHITTED_WAVES_KD : FRAY_WHITTED_WAVES); }
+#ifndef FRAY_WHITTED_CHILD_WAVES_KD
+#define FRAY_WHITTED_CHILD_WAVES_KD 3   // dragon Whitted 7.80 ms at 2 (180 VGPRs), 7.04 at 3 (168, 17 spilled), 6.98 at 4 (128, 105 spilled): pass B of the speculative fans (k_whitted<.., 2>: no pixel, no sample, no generator state) beside KD meshes
+#endif
+constexpr int whitted_waves(int st, int mode) { return mode == 2 && (st & 6) == 4 ? FRAY_WHITTED_CHILD_WAVES_KD : whitted_waves(st); }
 constexpr int primary_waves(int st) { return waves_for(st, kd_variant(st) ? FRAY_ANYHIT_WAVES_KD : FRAY_PRIMARY_WAVES); }
 constexpr int anyhit_waves(int st) { return waves_for(st, kd_variant(st) ? FRAY_ANYHIT_WAVES_KD : FRAY_SHADOW_WAVES); }
 
@@ -280,7 +284,7 @@ FD unsigned long long tile_now() { unsigned long long t; asm volatile("s_memtime
 static __global__ void k_add4(const int* __restrict__ a, int* __restrict__ sum) { if (threadIdx.x < 4) sum[threadIdx.x] += a[threadIdx.x]; }
 struct WhittedArgs { DScene S; DCamera C; DFrame F; int nItems; int s0, cn; float* rgb; float* rad; uint32_t* mtWork; const uint32_t* x397; DStats* st; DCursors* cur; SpecBuf sp; };
 template <int ST, int MODE>
-static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(WhittedArgs A)
+static __global__ __launch_bounds__(256, whitted_waves(ST, MODE)) void k_whitted(WhittedArgs A)
 {
     Cnt c = zero_cnt();
     MtLong tab;
@@ -487,9 +491,11 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
                     orthonormalSystem(n, bb, cc);
                     for (int q = 0; q < cnt; q++) {                           // the draws of shading.cpp:172-204, with nothing drawn in between
                         V3 reflected;
+                        int draws = 0;
                         for (;;) {
                             double dx, dy;
                             rng_unit_disc(tab, dx, dy);
+                            draws++;
                             dx *= sh.deflectionScaling;
                             dy *= sh.deflectionScaling;
                             const V3 nn = normalized(n + bb * dx + cc * dy);
@@ -497,6 +503,7 @@ static __global__ __launch_bounds__(256, whitted_waves(ST)) void k_whitted(Whitt
                             if (dot(reflected, n) > 0) break;
                         }
                         SP.cEntry[cb + q] = e;
+                        SP.cdraws[cb + q] = (unsigned char)(draws <= 255 ? draws : 0);
                         SP.cd[0][cb + q] = reflected.x; SP.cd[1][cb + q] = reflected.y; SP.cd[2][cb + q] = reflected.z;
                     }
                     L.sp = 0;

@@ -108,7 +108,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 // Speculative glossy fans (dev_whitted.hpp): three passes per batch, with room for one filed entry per camera sample and specFanMax children each.
                 // Not in the counting variants (their counters are the reference's call counts), not in stereo frames (the right eye continues the left eye's generator).
                 const int fan = (!(ST & 1) && sc->speculateFans && !(sc->camera.stereoSeparation > 0)) ? sc->specFanMax : 0;
-                const size_t perSample = 16 + (fan > 0 ? 32 + (size_t)fan * 41 : 0);
+                const size_t perSample = 16 + (fan > 0 ? 32 + (size_t)fan * 42 : 0);
                 int chunk = 0;
                 for (;;) {          // planned again with half the budget when the allocation fails (ensure_work_or_shrink)
                     const size_t wb = work_budget(sc);
@@ -118,7 +118,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     while (chunk > 1 && (size_t)nItems * chunk * (size_t)std::max(fan, 1) >= ((size_t)1 << 31)) chunk /= 2;
                     const size_t slots = (size_t)nItems * chunk, kids = slots * (size_t)fan;
                     const int rc = ensure_work_or_shrink(sc, colBytes + r256((size_t)nItems * 12) + r256(slots * 12) + r256(slots * 4) +
-                                                             (fan > 0 ? 256 + 2 * r256(slots * 4) + 3 * r256(slots * 8) + r256(kids * 4) + 3 * r256(kids * 8) + 3 * r256(kids * 4) + r256(kids) : 0));
+                                                             (fan > 0 ? 256 + 2 * r256(slots * 4) + 3 * r256(slots * 8) + r256(kids * 4) + 3 * r256(kids * 8) + 3 * r256(kids * 4) + 2 * r256(kids) : 0));
                     if (rc == FRAYHIP_RETRY_SMALLER && f->spp_chunk <= 0 && chunk > 1) continue;
                     if (rc) { if (rc == FRAYHIP_RETRY_SMALLER) return FRAYHIP_E_NOMEM; return rc; }
                     break;
@@ -141,6 +141,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     for (int q = 0; q < 3; q++) SPB.cd[q] = (double*)take(kids * 8);
                     for (int q = 0; q < 3; q++) SPB.cc[q] = (float*)take(kids * 4);
                     SPB.cok = take(kids);
+                    SPB.cdraws = take(kids);
                 }
                 for (int s0 = 0; s0 < spp; s0 += chunk) {
                     const int cn = std::min(chunk, spp - s0);
@@ -156,7 +157,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                             WhittedArgs WB = WA, WC = WA;
                             WB.cur = cursors + 1; WC.cur = cursors + 2;
                             hipLaunchKernelGGL((k_whitted<ST, 1>), dim3(grid), dim3(256), 0, stream, WA);     // samples; fans are filed
-                            hipLaunchKernelGGL((k_whitted<ST, 2>), dim3(grid), dim3(256), 0, stream, WB);     // the fans' children
+                            hipLaunchKernelGGL((k_whitted<ST, 2>), dim3(persistent_grid((size_t)nItems * cn * (size_t)fan, whitted_waves(ST, 2))), dim3(256), 0, stream, WB);     // the fans' children
                             hipLaunchKernelGGL((k_whitted<ST, 3>), dim3(grid), dim3(256), 0, stream, WC);     // the filed samples, children looked up
                         } else {
                             hipLaunchKernelGGL((k_whitted<ST, 0>), dim3(grid), dim3(256), 0, stream, WA);

@@ -1240,10 +1240,28 @@ static __global__ __launch_bounds__(256) void k_pt_resolve_terms(DFrame F, int n
         C3 a = s0 == 0 ? c3(0, 0, 0) : c3(sum[si], sum[si + 1], sum[si + 2]);
         for (int s = 0; s < chunk; s++) {
             const uint32_t slot = (uint32_t)s * (uint32_t)nItems + (uint32_t)item;
+            const int n = (int)TB.n[slot];
             C3 result = c3(0, 0, 0);
-            for (int k = (int)TB.n[slot] - 1; k >= 0; k--) {
-                const size_t q = (size_t)k * 3 * TB.nPaths + slot;
-                result = c3(TB.t[q], TB.t[q + TB.nPaths], TB.t[q + 2 * (size_t)TB.nPaths]) + result;
+            if (n <= 8) {
+                // up to eight terms (maxTraceDepth 6, the usual case): all their loads issued before the first addition -- with a loop whose length is
+                // the loaded count every term waited for the one before it (1.6 ms per 66 M samples at 1.8 TB/s, the kernel idle on latency)
+                float tr[8], tg[8], tb[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    tr[k] = tg[k] = tb[k] = 0.0f;
+                    if (k < n) {
+                        const size_t q = (size_t)k * 3 * TB.nPaths + slot;
+                        tr[k] = TB.t[q]; tg[k] = TB.t[q + TB.nPaths]; tb[k] = TB.t[q + 2 * (size_t)TB.nPaths];
+                    }
+                }
+#pragma unroll
+                for (int k = 7; k >= 0; k--)
+                    if (k < n) result = c3(tr[k], tg[k], tb[k]) + result;
+            } else {
+                for (int k = n - 1; k >= 0; k--) {
+                    const size_t q = (size_t)k * 3 * TB.nPaths + slot;
+                    result = c3(TB.t[q], TB.t[q + TB.nPaths], TB.t[q + 2 * (size_t)TB.nPaths]) + result;
+                }
             }
             a = a + result;
         }

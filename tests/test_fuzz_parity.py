@@ -233,6 +233,30 @@ def test_glossy_fans_scene(fray, abi, oracle, gpu):
     s.close()
 
 
+def test_recursive_whitted_in_batches_of_samples(fray, abi, oracle, gpu):
+    """k_whitted's work items are camera samples; a frame whose samples do not fit the budget is rendered in batches (here forced: spp_chunk 2 of 5),
+    each with its own tile cursors, speculation buffers and resolve.  Same picture as in one batch; the fans' figures add up over the batches."""
+    s = fray.Scene.parseScene(os.path.join(os.path.dirname(__file__), "scenes", "glossy_fans", "scene.fray"))
+    s.settings.wantAA = 1
+    s.beginRender()
+    whole, _ = s.render(seed=11)
+    filed = s.get_option("fans_filed")
+    parts, _ = s.render(seed=11, spp_chunk=2)
+    assert s.get_option("fans_filed") == filed > 0
+    assert np.array_equal(whole, parts)
+    s.set_option("speculate_fans", 0)
+    plain, _ = s.render(seed=11, spp_chunk=3)
+    assert np.array_equal(whole, plain)
+    s.camera.stereoSeparation = 0.2                         # anaglyph: both eyes in one work item, no speculation
+    s.beginRender()
+    a, _ = s.render(seed=11)
+    assert s.get_option("fans_filed") == 0
+    b, _ = s.render(seed=11, spp_chunk=1)
+    c, _ = s.render(seed=11, stats=True)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    s.close()
+
+
 def test_coincident_opposite_triangles(fray, abi, oracle, gpu, tmp_path):
     """tests/scenes/fuzz1009: the mesh `shard` holds the same triangle twice with opposite orientation and
     no back-face culling.  Both copies are hit at distances that differ in the last bits at most, so which

@@ -125,6 +125,15 @@ int bounce_grid(size_t n)
     return (int)(blocks < 1 ? 1 : blocks);
 }
 
+int seed_grid(size_t n)          // k_seed: many short threads
+{
+    static const long cap = getenv("FRAYHIP_SEED_BLOCKS") ? atol(getenv("FRAYHIP_SEED_BLOCKS")) : 32768;     // forest DOF 256: 155.2 ms at 2 048 blocks, 153.6 at 32 768 (a thread runs few chains and the last waves leave together)
+    size_t blocks = (n + 255) / 256;
+    if (blocks > (size_t)cap) blocks = (size_t)cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
 int grid_for(size_t n)
 {
     size_t blocks = (n + 255) / 256;

@@ -147,7 +147,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     const int cn = std::min(chunk, spp - s0);
                     if (s0 > 0) HIP_TRY(hipMemsetAsync(cursors, 0, 3 * sizeof(DCursors), stream));  // the tile cursors of the previous batch
                     if (fan > 0) HIP_TRY(hipMemsetAsync(SPB.counters, 0, s0 == 0 ? 256 : 32, stream));
-                    hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * cn + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
+                    hipLaunchKernelGGL(k_seed, dim3(seed_grid(((size_t)nItems * cn + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
                     hipEvent_t a = pool_event(sc->evPool, nTraceEvents), b = pool_event(sc->evPool, nTraceEvents + 1);
                     if (!a || !b) return FRAYHIP_E_NOMEM;
                     HIP_TRY(hipEventRecord(a, stream));
@@ -215,7 +215,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 for (int s0 = 0; s0 < spp; s0 += chunk) {
                     const int cn = std::min(chunk, spp - s0);
                     const size_t bs = (size_t)nItems * cn, bN = bs * eyes;      // this batch's slots: arrays are used with stride bN
-                    hipLaunchKernelGGL(k_seed, dim3(grid_for((bs + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
+                    hipLaunchKernelGGL(k_seed, dim3(seed_grid((bs + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
                     hipEvent_t ea = pool_event(sc->evPool, nTraceEvents), eb = pool_event(sc->evPool, nTraceEvents + 1);
                     hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
                     if (!ea || !eb || !ec || !ed) return FRAYHIP_E_NOMEM;
@@ -319,7 +319,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 const int cn = std::min(chunk, spp - s0);
                 Lane& L = lane[batch % nLanes];
                 hipStream_t ls = L.stream;
-                hipLaunchKernelGGL(k_seed, dim3(grid_for(((size_t)nItems * cn + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, ls, F, nItems, s0, cn, L.x397);
+                hipLaunchKernelGGL(k_seed, dim3(seed_grid(((size_t)nItems * cn + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, ls, F, nItems, s0, cn, L.x397);
                 for (int eye = 0; eye < (stereo ? 2 : 1); eye++) {
                     // A mono frame with register generators makes its camera rays inside the first bounce (k_pt_bounce<.., FIRST>); a stereo frame (the
                     // right eye continues the left eye's streams) and long generators start from a dense queue written by k_pt_init

@@ -86,6 +86,7 @@ enum { FRAYHIP_RETRY_SMALLER = 1 };      // internal: ensure_work_or_shrink halv
 int ensure_work_or_shrink(frayhip_scene* sc, size_t bytes);
 int bounce_grid(size_t n);
 int grid_for(size_t n);
+int seed_grid(size_t n);
 int ensure_work(frayhip_scene* sc, size_t bytes);
 // i-th event of a pool, created on first use; nullptr (and the error text set) when hipEventCreate fails
 hipEvent_t pool_event(std::vector<hipEvent_t>& pool, size_t i);

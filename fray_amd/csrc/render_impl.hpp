@@ -107,12 +107,14 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 const size_t colBytes = r256((size_t)grid * 256 * 624 * sizeof(uint32_t));
                 // Speculative glossy fans (dev_whitted.hpp): three passes per batch, with room for one filed entry per camera sample and specFanMax children each.
                 // Not in the counting variants (their counters are the reference's call counts), not in stereo frames (the right eye continues the left eye's generator).
-                const int fan = (!(ST & 1) && sc->speculateFans && !(sc->camera.stereoSeparation > 0)) ? sc->specFanMax : 0;
-                const size_t perSample = 16 + (fan > 0 ? 32 + (size_t)fan * 42 : 0);
+                int fan = (!(ST & 1) && sc->speculateFans && !(sc->camera.stereoSeparation > 0)) ? sc->specFanMax : 0;
                 int chunk = 0;
                 for (;;) {          // planned again with half the budget when the allocation fails (ensure_work_or_shrink)
                     const size_t wb = work_budget(sc);
                     const size_t budget = wb > colBytes + (64u << 20) ? wb - colBytes : (64u << 20);
+                    // a fan so large that one sample per pixel of it does not fit the budget (or 2^31 children) is not traced ahead
+                    if (fan > 0 && ((size_t)nItems * (48 + (size_t)fan * 42) > budget || (size_t)nItems * (size_t)fan >= ((size_t)1 << 31))) fan = 0;
+                    const size_t perSample = 16 + (fan > 0 ? 32 + (size_t)fan * 42 : 0);
                     chunk = f->spp_chunk > 0 ? f->spp_chunk : (int)std::max<size_t>(1, budget / ((size_t)nItems * perSample));
                     if (chunk > spp) chunk = spp;
                     while (chunk > 1 && (size_t)nItems * chunk * (size_t)std::max(fan, 1) >= ((size_t)1 << 31)) chunk /= 2;
@@ -123,7 +125,6 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     if (rc) { if (rc == FRAYHIP_RETRY_SMALLER) return FRAYHIP_E_NOMEM; return rc; }
                     break;
                 }
-                if (fan > 0 && (size_t)nItems * chunk * (size_t)fan >= ((size_t)1 << 31)) { set_error("frayhip_render: a glossy fan of this size does not fit one batch of this frame (set speculate_fans to 0)"); return FRAYHIP_E_UNSUPPORTED; }
                 unsigned char* p = (unsigned char*)sc->d_work;
                 auto take = [&](size_t b) { unsigned char* r = p; p += r256(b); return r; };
                 uint32_t* mtWork = (uint32_t*)take(colBytes);

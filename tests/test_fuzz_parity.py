@@ -247,6 +247,18 @@ def test_recursive_whitted_in_batches_of_samples(fray, abi, oracle, gpu):
     s.set_option("speculate_fans", 0)
     plain, _ = s.render(seed=11, spp_chunk=3)
     assert np.array_equal(whole, plain)
+    # a budget the fans' buffers do not fit: rendered without tracing ahead, in batches, same picture
+    s.settings.wantAA = 0
+    s.settings.frameWidth, s.settings.frameHeight = 480, 360
+    s.beginRender()
+    big, _ = s.render(seed=11)
+    assert s.get_option("fans_filed") > 0
+    s.set_option("pt_budget_mib", 1)
+    small, _ = s.render(seed=11)
+    assert s.get_option("fans_filed") == 0
+    assert np.array_equal(big, small)
+    s.settings.frameWidth, s.settings.frameHeight = 160, 120
+    s.settings.wantAA = 1
     s.camera.stereoSeparation = 0.2                         # anaglyph: both eyes in one work item, no speculation
     s.beginRender()
     a, _ = s.render(seed=11)

@@ -409,11 +409,12 @@ FD bool mesh_intersect(const FRAY_RO DMesh& M, LocalRay& lr, double& gamma, int&
                     bump<ST>(c.leafRefs);
                     const FRAY_RO DTri32* r = lf + base + t;
                     // Two forms of the same test.  As straight-line code (`sure_miss(...) & rayOk32`, the mask updated by a select) the compiler unrolls the loop by
-                    // two and packs the pair's FP32 operations: 3-7 % off the KD workloads.  The Cube / CSG kernel variants (flag bit 1: out-of-line calls, 100-350
-                    // spilled SGPRs next to 100-550 spilled VGPRs) keep the short circuit and the branch: with the straight-line form k_whitted<2> and k_pt_shadow<2>
-                    // rendered wrong pictures on fuzz scenes while their instrumented twins were right (profiles/r03_experiments/README.md E).  The variants without
-                    // that geometry pass 160 random KD scenes with it (both integrators, timed and instrumented kernels, hit records) and every fixture.
-                    if constexpr ((ST & 2) != 0 || !FRAY_FILTER_STRAIGHT) {
+                    // two and packs the pair's FP32 operations: 3-7 % off the KD workloads.  In round 3 the Cube / CSG kernel variants had to keep the short circuit
+                    // and the branch: with the straight-line form k_whitted<2> and k_pt_shadow<2> rendered wrong pictures on fuzz scenes while their instrumented
+                    // twins were right (profiles/r03_experiments/README.md E).  That was the compiler's greedy allocation of the whole-wave VGPRs holding spilled
+                    // SGPRs (the library is built with -wwm-regalloc=basic now): with it every variant takes the straight-line form and
+                    // passes the fuzz tests and 80 more Cube / CSG seeds (bokeh.fray 16.9 -> 16.0 ms).
+                    if constexpr (!FRAY_FILTER_STRAIGHT) {
                         const bool miss = rayOk32 && tri_sure_miss(r->A[0], r->A[1], r->A[2], r->AB[0], r->AB[1], r->AB[2], r->AC[0], r->AC[1], r->AC[2], r->Lq, r->Cq,
                                                                    s32x, s32y, s32z, d32x, d32y, d32z);
                         if (miss) bump<ST>(c.tri);           // the reference ran (and failed) its test on this one too

@@ -1,0 +1,8 @@
+#!/bin/bash
+# Development aid (GPU box): one rank's share of an N-rank headline frame under different numbers of batch lanes.   tools/shard_lanes.sh N lanes...
+N=$1; shift
+for v in "$@"; do
+  FRAYHIP_PT_LANES=$v timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-serial-pass --shard-of $N --shard-rank 1 > gpurun_out/shard_${N}_$v.json 2> /dev/null
+  python -c "
+import json;d=json.load(open('gpurun_out/shard_${N}_$v.json'));print('share of $N, lanes $v: %.3f ms' % d['ms_per_step'])"
+done

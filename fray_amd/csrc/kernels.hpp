@@ -281,7 +281,7 @@ FD unsigned long long tile_now() { unsigned long long t; asm volatile("s_memtime
 //                    they drew nothing; the first child that did draw is traced in place and so is everything after it, with the true generator state
 // Colours are added in the reference's order in pass C, by the same code; a child's colour does not depend on who traced it.  The counting variants
 // (flag bit 0) run MODE 0: their counters are the reference's call counts, and a re-run sample would count its camera ray twice.
-static __global__ void k_add4(const int* __restrict__ a, int* __restrict__ sum) { if (threadIdx.x < 4) sum[threadIdx.x] += a[threadIdx.x]; }
+static __global__ void k_add4(const int* __restrict__ a, unsigned long long* __restrict__ sum) { if (threadIdx.x < 4) sum[threadIdx.x] += (unsigned long long)a[threadIdx.x]; }   // a frame's totals over its batches may pass 2^31
 struct WhittedArgs { DScene S; DCamera C; DFrame F; int nItems; int s0, cn; float* rgb; float* rad; uint32_t* mtWork; const uint32_t* x397; DStats* st; DCursors* cur; SpecBuf sp; };
 template <int ST, int MODE>
 static __global__ __launch_bounds__(256, whitted_waves(ST, MODE)) void k_whitted(WhittedArgs A)

@@ -82,7 +82,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     DCursors* cursors = (DCursors*)((unsigned char*)sc->d_stats + kCursorOffset);
     HIP_TRY(hipEventRecord(sc->evA, stream));
     size_t nTraceEvents = 0, nShadowEvents = 0;
-    const int* fanTotals = nullptr;          // device: the speculative fans' counters summed over the frame's batches
+    const unsigned long long* fanTotals = nullptr;          // device: the speculative fans' counters summed over the frame's batches
 
     if (f->mode == FRAYHIP_MODE_PRIMARY_ID) {
         if (nItems > 0) {
@@ -169,9 +169,9 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     HIP_TRY(hipEventRecord(b, stream));
                     nTraceEvents += 2;
                     if (spp > 1) hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, stream, F, C, set.saturation, nItems, s0, cn, rad, (const float*)nullptr, sum, d_rgb);
-                    if (fan > 0) hipLaunchKernelGGL(k_add4, dim3(1), dim3(64), 0, stream, SPB.counters, SPB.counters + 8);       // the frame's totals over its batches
+                    if (fan > 0) hipLaunchKernelGGL(k_add4, dim3(1), dim3(64), 0, stream, SPB.counters, (unsigned long long*)(SPB.counters + 8));       // the frame's totals over its batches
                 }
-                fanTotals = fan > 0 ? SPB.counters + 8 : nullptr;
+                fanTotals = fan > 0 ? (const unsigned long long*)(SPB.counters + 8) : nullptr;
             } else if (nItems > 0) {
                 // Wavefront Whitted (no recursive shader in the scene): batches of `chunk` samples per pixel through
                 // k_wh_shade -> k_wh_visible -> k_wh_gather, then the ordered per-pixel sum (k_pt_resolve).
@@ -381,9 +381,9 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     DStats dsv[2];
     HIP_TRY(hipMemcpy(dsv, sc->d_stats, sizeof dsv, hipMemcpyDeviceToHost));
     {
-        int ft[4] = {0, 0, 0, 0};
+        unsigned long long ft[4] = {0, 0, 0, 0};
         if (fanTotals) HIP_TRY(hipMemcpy(ft, fanTotals, sizeof ft, hipMemcpyDeviceToHost));
-        for (int q = 0; q < 4; q++) sc->lastFans[q] = ft[q];
+        for (int q = 0; q < 4; q++) sc->lastFans[q] = (long long)ft[q];
     }
 #ifdef FRAY_LEAFSTAT
     {

@@ -425,7 +425,9 @@ def main():
             "config": {"workload": desc_text, "width": W, "height": H, "spp": scene.samples_per_pixel(),
                        "rays_per_frame": rays_total, "camera_samples_per_frame": float(counts[2]),
                        "parallelism": "tiles%d" % world if world > 1 else ("rank %d's share of tiles%d, no exchange (diagnosis)" % (args.shard_rank, args.shard_of) if args.shard_of > 1 else "single-gpu"),
-                       "frame_ms": ms_per_step, "msamples_per_s": float(counts[2]) / (ms_per_step * 1e-3) / 1e6},
+                       "frame_ms": ms_per_step, "msamples_per_s": float(counts[2]) / (ms_per_step * 1e-3) / 1e6,
+                       # glossy fans drawn and traced ahead in the last timed frame (frayhip_scene_get_option; zero unless the scene has such fans and no sampling light)
+                       "speculative_fans": {k: scene.get_option(k) for k in ("fans_filed", "fan_children", "fan_children_looked_up", "fans_given_up")}},
             # What bounds the dominant kernel is FP64 vector issue, not HBM: algorithmic FP64
             # operations per launch (SURVEY 8d operation counts x this frame's work counters) / average launch duration.
             "roofline": {"bound": "fp64_valu", "kernel": kern, "achieved": tf, "peak": FP64_PEAK, "unit": "TFLOP/s", "frac": tf / FP64_PEAK,

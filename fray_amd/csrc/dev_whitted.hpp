@@ -134,18 +134,20 @@ FD void wl_cheap_step(const DScene& S, WhittedLane& L, G& tab, Cnt& c, bool& ove
             if (MODE == 3 && SL.state == 1 && SL.sp == L.sp - 1) SL.state = 2;
             L.ret = f.acc / (float)f.count; L.sp--; L.mode = WM_RET; return;
         }
-        if (MODE == 3 && SL.state == 1 && SL.sp == L.sp - 1) {  // the filed fan: this child's raytrace() ran in pass B, from the ray pass A drew for it, unless a draw came in between
-            const int ch = SL.base + f.i;
-            const int it = SP.cdraws[ch];
-            if (SP.cok[ch] && it) {
+        if (MODE == 3 && SL.state == 1 && SL.sp == L.sp - 1) {  // the filed fan: its children's raytrace() calls ran in pass B, from the rays pass A drew for them, unless a draw came in between
+            const C3 mult = ldc(sh.mult);
+            while (f.i < f.count) {                             // as many of them as drew nothing, in one go: the loop of shading.cpp:172-204 with raytrace() looked up
+                const int ch = SL.base + f.i;
+                const int it = SP.cdraws[ch];
+                if (!(SP.cok[ch] && it)) break;
                 for (int q = 0; q < 4 * it; q++) (void)tab.next();  // the words of its unit-disc samples (two doubles each)
                 SL.looked++;
-                L.ret = c3(SP.cc[0][ch], SP.cc[1][ch], SP.cc[2][ch]);
-                L.mode = WM_RET;
-                return;
+                f.acc = f.acc + c3(SP.cc[0][ch], SP.cc[1][ch], SP.cc[2][ch]) * mult;
+                f.i++;
             }
+            if (f.i == f.count) { SL.state = 2; L.ret = f.acc / (float)f.count; L.sp--; L.mode = WM_RET; return; }
             SL.missed++;
-            SL.state = 2;                                       // it drew: from here on the generator is not where pass A assumed it
+            SL.state = 2;                                       // child f.i drew: from here on the generator is not where pass A assumed it, and the fan goes on as usual
         }
         V3 n = faceforward(f.d, f.info.norm);
         V3 b, cc;

@@ -64,7 +64,10 @@ constexpr int whitted_waves(int st) { return waves_for(st, (st & 6) == 4 ? FRAY_
 #ifndef FRAY_WHITTED_CHILD_WAVES_KD
 #define FRAY_WHITTED_CHILD_WAVES_KD 3   // dragon Whitted 7.80 ms at 2 (180 VGPRs), 7.04 at 3 (168, 17 spilled), 6.98 at 4 (128, 105 spilled): pass B of the speculative fans (k_whitted<.., 2>: no pixel, no sample, no generator state) beside KD meshes
 #endif
-constexpr int whitted_waves(int st, int mode) { return mode == 2 && (st & 6) == 4 ? FRAY_WHITTED_CHILD_WAVES_KD : whitted_waves(st); }
+#ifndef FRAY_WHITTED_AC_WAVES_KD
+#define FRAY_WHITTED_AC_WAVES_KD 3      // passes A and C beside KD meshes: dragon Whitted 6.45 ms at 2, 6.33 at 3 (72 / 91 spilled), 6.56 at 4
+#endif
+constexpr int whitted_waves(int st, int mode) { return (st & 6) != 4 || mode == 0 ? whitted_waves(st) : mode == 2 ? FRAY_WHITTED_CHILD_WAVES_KD : FRAY_WHITTED_AC_WAVES_KD; }
 constexpr int primary_waves(int st) { return waves_for(st, kd_variant(st) ? FRAY_ANYHIT_WAVES_KD : FRAY_PRIMARY_WAVES); }
 constexpr int anyhit_waves(int st) { return waves_for(st, kd_variant(st) ? FRAY_ANYHIT_WAVES_KD : FRAY_SHADOW_WAVES); }
 

@@ -103,8 +103,9 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 // (pixel, sample) of a batch the sample's colour and x[397] of its seed.  A work item of k_whitted is one camera sample, so the
                 // grid is sized by the samples, and a frame whose samples do not fit the budget (or 2^31 items) is rendered in batches of `chunk` samples per pixel.
                 auto r256 = [](size_t b) { return (b + 255) / 256 * 256; };
-                const int grid = persistent_grid((size_t)nItems * spp, whitted_waves(ST));
-                const size_t colBytes = r256((size_t)grid * 256 * 624 * sizeof(uint32_t));
+                const int grid = persistent_grid((size_t)nItems * spp, whitted_waves(ST));                 // one pass
+                const int gridAC = persistent_grid((size_t)nItems * spp, whitted_waves(ST, 1));            // passes A and C of the speculative fans
+                const size_t colBytes = r256((size_t)std::max(grid, gridAC) * 256 * 624 * sizeof(uint32_t));
                 // Speculative glossy fans (dev_whitted.hpp): three passes per batch, with room for one filed entry per camera sample and specFanMax children each.
                 // Not in the counting variants (their counters are the reference's call counts), not in stereo frames (the right eye continues the left eye's generator).
                 int fan = (!(ST & 1) && sc->speculateFans && !(sc->camera.stereoSeparation > 0)) ? sc->specFanMax : 0;
@@ -157,9 +158,9 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                         if (fan > 0) {
                             WhittedArgs WB = WA, WC = WA;
                             WB.cur = cursors + 1; WC.cur = cursors + 2;
-                            hipLaunchKernelGGL((k_whitted<ST, 1>), dim3(grid), dim3(256), 0, stream, WA);     // samples; fans are filed
+                            hipLaunchKernelGGL((k_whitted<ST, 1>), dim3(gridAC), dim3(256), 0, stream, WA);   // samples; fans are filed
                             hipLaunchKernelGGL((k_whitted<ST, 2>), dim3(persistent_grid((size_t)nItems * cn * (size_t)fan, whitted_waves(ST, 2))), dim3(256), 0, stream, WB);     // the fans' children
-                            hipLaunchKernelGGL((k_whitted<ST, 3>), dim3(grid), dim3(256), 0, stream, WC);     // the filed samples, children looked up
+                            hipLaunchKernelGGL((k_whitted<ST, 3>), dim3(gridAC), dim3(256), 0, stream, WC);   // the filed samples, children looked up
                         } else {
                             hipLaunchKernelGGL((k_whitted<ST, 0>), dim3(grid), dim3(256), 0, stream, WA);
                         }

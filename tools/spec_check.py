@@ -1,5 +1,6 @@
+"""Development aid (GPU box): a scene rendered with and without speculative glossy fans (option speculate_fans): identical pictures? kernel times."""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import fray_amd
 def run(path, W, H, spec, reps=1):
     s = fray_amd.Scene.parseScene(path)

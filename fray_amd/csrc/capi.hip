@@ -117,11 +117,18 @@ int persistent_grid(size_t n, int wavesPerSimd)
 #ifndef FRAY_BOUNCE_BLOCKS
 #define FRAY_BOUNCE_BLOCKS 2048
 #endif
-static_assert(FRAY_BOUNCE_BLOCKS * 4 <= FRAY_MAXSEG, "every wave of the bounce / shadow grid owns one segment of the queue tables (QMeta)");
-int bounce_grid(size_t n)
+#ifndef FRAY_BOUNCE_BLOCKS_ALONE
+#define FRAY_BOUNCE_BLOCKS_ALONE 8192
+#endif
+static_assert(FRAY_BOUNCE_BLOCKS * 4 <= FRAY_MAXSEG && FRAY_BOUNCE_BLOCKS_ALONE * 4 <= FRAY_MAXSEG, "every wave of the bounce / shadow grid owns one segment of the queue tables (QMeta)");
+// Every wave of the bounce / shadow grid gets an equal share of the queue.  With four batches in flight the frame is fastest at 2 048 blocks (smaller shares add
+// instructions, and the other lanes' blocks fill a launch's tail anyway: profiles/r04_experiments/README.md K).  The Cube / CSG variants run their batches one at a time
+// (`alone`), where the tail is the chip standing empty: 8 192 blocks, csg_nested path traced 79.8 -> 67.4 ms.
+int bounce_grid(size_t n, bool alone)
 {
     size_t blocks = (n + 255) / 256;
-    if (blocks > FRAY_BOUNCE_BLOCKS) blocks = FRAY_BOUNCE_BLOCKS;
+    const size_t cap = alone ? FRAY_BOUNCE_BLOCKS_ALONE : FRAY_BOUNCE_BLOCKS;
+    if (blocks > cap) blocks = cap;
     return (int)(blocks < 1 ? 1 : blocks);
 }
 

@@ -46,7 +46,7 @@ struct TermBuf {
 };
 
 #ifndef FRAY_MAXSEG
-#define FRAY_MAXSEG 8192   // = 2048 blocks x 4 waves, the largest grid grid_for() returns
+#define FRAY_MAXSEG 32768  // = 8192 blocks x 4 waves, the largest grid bounce_grid() returns (the Cube / CSG variants, whose batches run one at a time)
 #endif
 // A producing wave owns one segment of `chunk` entries and fills it from BOTH ends: rays that miss every gate (dev_scene.hpp DGate) from the
 // front, the others from the back.  cnt[w] = entries of wave w's segment, nf[w] = how many of them sit at the front; entry e of the segment

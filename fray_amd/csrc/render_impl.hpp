@@ -269,7 +269,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 nLanes = std::min(nBatches, maxLanes);
                 nPaths = (size_t)nItems * chunk;
                 // per-wave segments round their share up to a multiple of 64: one extra wave-load per wave of the grid
-                nQueue = nPaths + (size_t)grid_for(nPaths) * 4 * 128;
+                nQueue = nPaths + (size_t)bounce_grid(nPaths, (ST & 2) != 0) * 4 * 128;
                 laneBytes = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + nPaths * 4 + 4096 + nPaths * termBytes + 512 + (longRng ? nPaths * 2 * 624 * sizeof(uint32_t) + 256 : 0) +
                             (stereo ? nPaths * (12 + 6 * 8 + 6 * 4) + 16 * 256 : 0);
                 const int rc = ensure_work_or_shrink(sc, (size_t)nLanes * laneBytes + (size_t)nItems * 12 + 4096);
@@ -337,7 +337,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     }
                     for (int b = 0; b < nBounce; b++) {
                         const QMetaRO mIn{(const FRAY_RO QMeta*)(L.meta + (b & 1))}, mSh{(const FRAY_RO QMeta*)(L.meta + 2)};
-                        const int grid = bounce_grid((size_t)nItems * cn);
+                        const int grid = bounce_grid((size_t)nItems * cn, (ST & 2) != 0);
                         hipEvent_t ea = pool_event(sc->evPool, nTraceEvents), eb = pool_event(sc->evPool, nTraceEvents + 1);
                         hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
                         if (!ea || !eb || !ec || !ed) return FRAYHIP_E_NOMEM;

@@ -84,7 +84,7 @@ int persistent_grid(size_t n, int wavesPerSimd);
 size_t work_budget(frayhip_scene* sc);
 enum { FRAYHIP_RETRY_SMALLER = 1 };      // internal: ensure_work_or_shrink halved the budget, plan the frame again
 int ensure_work_or_shrink(frayhip_scene* sc, size_t bytes);
-int bounce_grid(size_t n);
+int bounce_grid(size_t n, bool alone);
 int grid_for(size_t n);
 int seed_grid(size_t n);
 int ensure_work(frayhip_scene* sc, size_t bytes);

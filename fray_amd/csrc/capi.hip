@@ -124,10 +124,12 @@ static_assert(FRAY_BOUNCE_BLOCKS * 4 <= FRAY_MAXSEG && FRAY_BOUNCE_BLOCKS_ALONE 
 // Every wave of the bounce / shadow grid gets an equal share of the queue.  With four batches in flight the frame is fastest at 2 048 blocks (smaller shares add
 // instructions, and the other lanes' blocks fill a launch's tail anyway: profiles/r04_experiments/README.md K).  The Cube / CSG variants run their batches one at a time
 // (`alone`), where the tail is the chip standing empty: 8 192 blocks, csg_nested path traced 79.8 -> 67.4 ms.
+// Beside other batches a block should get at least 8 192 paths (2 048 per wave): one rank's share of an 8-rank frame (5.7 M paths per batch) is fastest at 768-1 024 blocks
+// (12.6-12.7 ms against 13.3 at 2 048, 15.9 at 4 096), a quarter frame at 1 024-1 536, the whole frame (16.6 M) at 2 048.
 int bounce_grid(size_t n, bool alone)
 {
     size_t blocks = (n + 255) / 256;
-    const size_t cap = alone ? FRAY_BOUNCE_BLOCKS_ALONE : FRAY_BOUNCE_BLOCKS;
+    const size_t cap = alone ? (size_t)FRAY_BOUNCE_BLOCKS_ALONE : std::min<size_t>(FRAY_BOUNCE_BLOCKS, std::max<size_t>(256, n / 8192));
     if (blocks > cap) blocks = cap;
     return (int)(blocks < 1 ? 1 : blocks);
 }

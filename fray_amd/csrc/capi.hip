@@ -117,6 +117,9 @@ int persistent_grid(size_t n, int wavesPerSimd)
 #ifndef FRAY_BOUNCE_BLOCKS
 #define FRAY_BOUNCE_BLOCKS 2048
 #endif
+#ifndef FRAY_BOUNCE_PATHS_PER_BLOCK
+#define FRAY_BOUNCE_PATHS_PER_BLOCK 8192
+#endif
 #ifndef FRAY_BOUNCE_BLOCKS_ALONE
 #define FRAY_BOUNCE_BLOCKS_ALONE 8192
 #endif
@@ -129,7 +132,7 @@ static_assert(FRAY_BOUNCE_BLOCKS * 4 <= FRAY_MAXSEG && FRAY_BOUNCE_BLOCKS_ALONE 
 int bounce_grid(size_t n, bool alone)
 {
     size_t blocks = (n + 255) / 256;
-    const size_t cap = alone ? (size_t)FRAY_BOUNCE_BLOCKS_ALONE : std::min<size_t>(FRAY_BOUNCE_BLOCKS, std::max<size_t>(256, n / 8192));
+    const size_t cap = alone ? (size_t)FRAY_BOUNCE_BLOCKS_ALONE : std::min<size_t>(FRAY_BOUNCE_BLOCKS, std::max<size_t>(256, n / FRAY_BOUNCE_PATHS_PER_BLOCK));
     if (blocks > cap) blocks = cap;
     return (int)(blocks < 1 ? 1 : blocks);
 }

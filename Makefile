@@ -27,7 +27,7 @@ VARIANT_OBJ := $(foreach st,0 1 2 3 4 5 8 9,fray_amd/csrc/variant$(st).o)
 HIP_OBJ  := fray_amd/csrc/capi.o fray_amd/csrc/capi_comm.o $(VARIANT_OBJ)
 HIP_HDR  := $(wildcard fray_amd/csrc/*.h) $(wildcard fray_amd/csrc/*.hpp) include/frayhip.h
 
-all: fray_amd/libfrayhip.so oracle/libfray_oracle.so examples/fray_render examples/fray_render_mgpu ref
+all: fray_amd/libfrayhip.so oracle/libfray_oracle.so examples/fray_render examples/fray_render_mgpu tests/native/librccl_loopback.so ref
 
 fray_amd/csrc/%.o: fray_amd/csrc/%.cpp $(HIP_HDR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
@@ -54,6 +54,11 @@ examples/fray_render: examples/fray_render.cpp include/frayhip.h fray_amd/libfra
 examples/fray_render_mgpu: examples/fray_render_mgpu.cpp include/frayhip.h fray_amd/libfrayhip.so
 	$(CXX) -O2 -std=c++17 -Iinclude -I/opt/rocm/include $< -o $@ -Lfray_amd -lfrayhip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../fray_amd' -Wl,-rpath,/opt/rocm/lib
 
+# TEST INFRASTRUCTURE: a loopback stand-in for the RCCL entry points the library binds, so that frayhip_gather_buckets' world > 1 branch can
+# execute on a one-GPU box (tests/test_gpu_gather_loopback.py names it in FRAYHIP_RCCL_LIBRARY; the product never loads it otherwise)
+tests/native/librccl_loopback.so: tests/native/rccl_loopback.cpp
+	$(CXX) -O2 -std=c++17 -fPIC -shared -I/opt/rocm/include $< -o $@ -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
+
 # Partial reference build: only when the reference tree is mounted (never on the GPU box).
 ref:
 	@if [ -d /root/reference/src ]; then $(MAKE) -C oracle -f Makefile.ref; else echo "reference tree absent: oracle/_ref not rebuilt"; fi
@@ -62,7 +67,7 @@ resources: $(VARIANT_OBJ)
 	python3 tools/kernel_resources.py fray_amd/csrc/variant*.resources.txt
 
 clean:
-	rm -f fray_amd/csrc/*.o fray_amd/csrc/*.resources.txt fray_amd/libfrayhip.so oracle/libfray_oracle.so examples/fray_render examples/fray_render_mgpu
+	rm -f fray_amd/csrc/*.o fray_amd/csrc/*.resources.txt fray_amd/libfrayhip.so oracle/libfray_oracle.so examples/fray_render examples/fray_render_mgpu tests/native/librccl_loopback.so
 	rm -rf oracle/_ref
 
 .PHONY: all ref clean resources

@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--shard-of", type=int, default=0, help="diagnosis on one GPU: render only ONE rank's share of an N-rank run (buckets r mod N, r = --shard-rank), no exchange")
     ap.add_argument("--shard-rank", type=int, default=0, help="with --shard-of N: whose share (tools/shard_balance.py measures every rank's)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the real multi-GPU run) or gloo (rehearsal: N ranks sharing GPU 0)")
+    ap.add_argument("--library-gather", action="store_true", help="with --backend gloo: still exchange through frayhip_gather_buckets (the library binds whatever RCCL "
+                    "FRAYHIP_RCCL_LIBRARY names -- on a one-GPU box the test suite's loopback stand-in, since RCCL itself refuses two ranks on one device)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -247,7 +249,7 @@ def main():
     libgather = None
     if world > 1:
         ok = 0
-        if args.backend == "nccl" and not args.torch_gather:
+        if (args.backend == "nccl" or args.library_gather) and not args.torch_gather:
             try:
                 libgather = tiles.LibraryGather(rank, world, dist)
                 ok = 1
@@ -264,11 +266,11 @@ def main():
             except Exception as e:                 # noqa: BLE001
                 sys.stderr.write("rank %d: library gather failed on its first exchange (%s)\n" % (rank, e))
                 ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag[0]) == 1:
             gatherer = gather_ids = gather_dist = libgather
-            transport = "frayhip_gather_buckets (RCCL ncclSend/ncclRecv, peer -> root)"
+            transport = "frayhip_gather_buckets (RCCL ncclSend/ncclRecv, peer -> root; bound from %s)" % (lib.frayhip_comm_library().decode() or "?")
         else:
             stage = args.backend != "nccl"
             gatherer = tiles.TileGather(W, H, 3, rank, world, dev, dist, stage_host=stage)

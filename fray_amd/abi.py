@@ -170,6 +170,7 @@ SYMBOLS = {
     "frayhip_unpack_buckets_device": (C.c_int, [VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "frayhip_bucket_xy": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "frayhip_comm_available": (C.c_int, []),
+    "frayhip_comm_library": (C.c_char_p, []),
     "frayhip_comm_unique_id": (C.c_int, [VP]),
     "frayhip_comm_create": (C.c_int, [VP, C.c_int, C.c_int, P(VP)]),
     "frayhip_comm_from_nccl": (C.c_int, [VP, C.c_int, C.c_int, P(VP)]),

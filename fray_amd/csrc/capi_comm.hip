@@ -34,7 +34,7 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
-    std::string why;
+    std::string why, path;          // why binding failed; the file ncclCommInitRank was bound from
 };
 
 Rccl* rccl()
@@ -45,9 +45,16 @@ Rccl* rccl()
         // A process that already holds an RCCL (PyTorch maps its own copy) must keep exactly one: first ask for the copy that is
         // already loaded (RTLD_NOLOAD binds it without loading anything), and only then load one.
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // FRAYHIP_RCCL_LIBRARY names the RCCL build to bind (a deployment's own build; the loopback stand-in of the test suite): it wins over
+        // whatever the process holds, is loaded RTLD_LOCAL so that it shadows nobody else's symbols, and nothing else is tried when it fails.
+        const char* forced = getenv("FRAYHIP_RCCL_LIBRARY");
+        if (forced && *forced) {
+            r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!r.lib) { r.why = std::string("FRAYHIP_RCCL_LIBRARY: ") + dlerror(); return; }
+        }
         for (const char* n : names) {
-            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
             if (r.lib) break;
+            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
         }
         if (!r.lib && dlsym(RTLD_DEFAULT, "ncclCommInitRank")) r.lib = dlopen(nullptr, RTLD_NOW);   // linked into the process under another name
         for (const char* n : names) {
@@ -66,6 +73,8 @@ Rccl* rccl()
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
         r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
         r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
+        Dl_info info;
+        if (r.CommInitRank && dladdr((void*)r.CommInitRank, &info) && info.dli_fname) r.path = info.dli_fname;
     });
     return r.why.empty() ? &r : nullptr;
 }
@@ -225,6 +234,14 @@ int frayhip_comm_ranks(frayhip_comm* c)
     int n = 0;
     NCCL_TRY(R->CommCount(c->comm, &n));
     return n;
+}
+
+// The file the RCCL entry points were bound from (dladdr of ncclCommInitRank): what a host logs to say WHICH RCCL carried its frames --
+// the copy PyTorch mapped, the system's, or the one FRAYHIP_RCCL_LIBRARY named.  "" when RCCL cannot be bound.
+const char* frayhip_comm_library(void)
+{
+    Rccl* R = rccl();
+    return R ? R->path.c_str() : "";
 }
 
 // Can this host exchange through RCCL at all?  Every rank asks before any rank enters ncclCommInitRank (which blocks until all

@@ -336,12 +336,15 @@ int  frayhip_unpack_buckets_device(const float* d_packed, float* d_frame, int wi
  *                            RCCL), negative error code on failure: what a host prints to show that the exchange really spans N GPUs
  *   frayhip_comm_available   1 when RCCL can be bound in this process, 0 otherwise: frayhip_comm_create blocks inside
  *                            ncclCommInitRank until EVERY rank has entered it, so the ranks agree on this first
- * RCCL is bound at run time (an RCCL the process already holds is used, none is loaded beside it): FRAYHIP_E_UNSUPPORTED
+ *   frayhip_comm_library     the file the RCCL entry points were bound from ("" when none could be): which RCCL carries the frames
+ * RCCL is bound at run time (an RCCL the process already holds is used, none is loaded beside it; the environment variable
+ * FRAYHIP_RCCL_LIBRARY, read at the first comm call, names a specific build to bind instead): FRAYHIP_E_UNSUPPORTED
  * when the host has none.  Gathers on one communicator share its staging buffer; a gather waits, on its own stream,
  * for the previous gather of that communicator, so they may be issued on different streams. */
 #define FRAYHIP_COMM_ID_BYTES 128
 typedef struct frayhip_comm frayhip_comm;
 int  frayhip_comm_available(void);
+const char* frayhip_comm_library(void);
 int  frayhip_comm_unique_id(void* id128);
 int  frayhip_comm_create(const void* id128, int rank, int world, frayhip_comm** out);
 int  frayhip_comm_from_nccl(void* nccl_comm, int rank, int world, frayhip_comm** out);

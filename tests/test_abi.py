@@ -195,3 +195,22 @@ def test_build_recipe_keeps_what_correctness_depends_on(fray):
     syms = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
     names = {l.split()[-1].split("@")[0] for l in syms.splitlines() if l.strip()}
     assert "sincos" in names and "sin" not in names and "cos" not in names, sorted(n for n in names if n in ("sin", "cos", "sincos"))
+
+
+def test_loopback_stand_in_exports_what_the_library_binds():
+    """tests/native/librccl_loopback.so (test infrastructure for tests/test_gpu_gather_loopback.py) must offer every RCCL entry point
+    fray_amd/csrc/capi_comm.hip binds, and FRAYHIP_RCCL_LIBRARY must make the library bind it (no GPU needed for either)."""
+    import subprocess
+    import sys
+    so = os.path.join(ROOT, "tests", "native", "librccl_loopback.so")
+    assert os.path.exists(so), "not built (make)"
+    bound = re.findall(r'sym\("(nccl\w+)"\)', open(os.path.join(ROOT, "fray_amd", "csrc", "capi_comm.hip")).read())
+    assert len(bound) == 10
+    lib = C.CDLL(so)
+    for n in bound:
+        assert hasattr(lib, n), n
+    code = "import fray_amd; print(fray_amd.lib.frayhip_comm_available(), fray_amd.lib.frayhip_comm_library().decode())"
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env={**os.environ, "FRAYHIP_RCCL_LIBRARY": so}, capture_output=True, text=True, timeout=300)
+    assert r.stdout.split() == ["1", so], r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env={**os.environ, "FRAYHIP_RCCL_LIBRARY": "/nonexistent/librccl.so"}, capture_output=True, text=True, timeout=300)
+    assert r.stdout.split() == ["0"], r.stdout + r.stderr            # a named build that cannot be loaded is an error, not a reason to bind another

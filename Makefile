@@ -24,7 +24,9 @@ HOST_OBJ := $(HOST_SRC:.cpp=.o)
 # render_variant.hip is compiled once per kernel flag word (render_impl<0..5, 8, 9>): eight independent translation
 # units that `make -j` builds side by side
 VARIANT_OBJ := $(foreach st,0 1 2 3 4 5 8 9,fray_amd/csrc/variant$(st).o)
-HIP_OBJ  := fray_amd/csrc/capi.o fray_amd/csrc/capi_comm.o $(VARIANT_OBJ)
+# render_contract.hip: the path tracer's bounce / shadow kernels once more per flag word, built with fused multiply-adds (option "fp_contract")
+CONTRACT_OBJ := $(foreach st,0 1 4 5 8 9,fray_amd/csrc/variantC$(st).o)
+HIP_OBJ  := fray_amd/csrc/capi.o fray_amd/csrc/capi_comm.o $(VARIANT_OBJ) $(CONTRACT_OBJ)
 HIP_HDR  := $(wildcard fray_amd/csrc/*.h) $(wildcard fray_amd/csrc/*.hpp) include/frayhip.h
 
 all: fray_amd/libfrayhip.so oracle/libfray_oracle.so examples/fray_render examples/fray_render_mgpu tests/native/librccl_loopback.so ref
@@ -39,6 +41,10 @@ fray_amd/csrc/%.o: fray_amd/csrc/%.hip $(HIP_HDR)
 # next to the object; `make resources` gathers them into profiles/)
 fray_amd/csrc/variant%.o: fray_amd/csrc/render_variant.hip $(HIP_HDR)
 	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -DFRAY_ST=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> fray_amd/csrc/variant$*.resources.txt || (cat fray_amd/csrc/variant$*.resources.txt; false)
+
+# (the last -ffp-contract on the command line wins)
+fray_amd/csrc/variantC%.o: fray_amd/csrc/render_contract.hip $(HIP_HDR)
+	$(HIPCC) $(HIPFLAGS) $(EXTRA_HIPFLAGS) -ffp-contract=fast -DFRAY_ARITH=1 -DFRAY_ST=$* -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> fray_amd/csrc/variantC$*.resources.txt || (cat fray_amd/csrc/variantC$*.resources.txt; false)
 
 fray_amd/libfrayhip.so: $(HOST_OBJ) $(HIP_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl

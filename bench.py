@@ -68,7 +68,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0, gpu_frame=None):
+def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0, gpu_frame=None, other_frames=None):
     """The oracle (a scalar C++ port of the reference path) timed on this box's host cores on a
     bounded sample of the same workload: every `stride`-th 48x48 bucket of the same frame."""
     from oracle.oracle import Oracle
@@ -90,6 +90,7 @@ def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0, gpu_frame=None):
     cpu_img, st = orc.render(s.desc, mode, seed=seed, bucket_first=0, bucket_stride=stride, threads=threads)
     dt = time.time() - t0
     parity = None
+    other_parity = {}
     if gpu_frame is not None:
         # the buckets the oracle just rendered, against the same pixels of the frame the GPU was timed on
         import numpy as np
@@ -99,9 +100,15 @@ def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0, gpu_frame=None):
             bx, by = tiles.bucket_xy(W, H, b)
             mask[by * 48:by * 48 + 48, bx * 48:bx * 48 + 48] = True
         d = gpu_frame[mask].astype(np.float64) - cpu_img[mask]
-        parity = {"pixels": int(mask.sum()), "rms_per_channel": [float(v) for v in np.sqrt((d ** 2).mean(axis=0))],
-                  "max_abs": float(np.abs(d).max()), "tolerance": 1e-4,
-                  "bit_identical_pixels": float((gpu_frame[mask] == cpu_img[mask]).all(axis=1).mean())}
+        def against_oracle(img):
+            d = img[mask].astype(np.float64) - cpu_img[mask]
+            return {"pixels": int(mask.sum()), "rms_per_channel": [float(v) for v in np.sqrt((d ** 2).mean(axis=0))],
+                    "max_abs": float(np.abs(d).max()), "tolerance": 1e-4,
+                    "bit_identical_pixels": float((img[mask] == cpu_img[mask]).all(axis=1).mean())}
+        parity = against_oracle(gpu_frame)
+        # frames of the same workload rendered in another arithmetic mode (option "fp_contract"): the same buckets against the same oracle pixels
+        for k, img in (other_frames or {}).items():
+            other_parity[k] = against_oracle(img)
     rays = st["closest_rays"] + st["shadow_rays"]
     n_b = len(range(0, nb, stride))
     # single-thread figure on a smaller sample (~4 s)
@@ -112,6 +119,7 @@ def cpu_baseline(fray_amd, abi, wl, seed, target_seconds=12.0, gpu_frame=None):
     s.close()
     ref_cmp = reference_object_code_rate(fray_amd, abi, orc, wl, seed)
     return {**({"reference_object_code": ref_cmp} if ref_cmp else {}), **({"gpu_frame_vs_oracle_on_the_sample": parity} if parity else {}),
+            **({"other_frames_vs_oracle_on_the_sample": other_parity} if other_parity else {}),
             "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": "%d of %d buckets (every %d-th 48x48 bucket) of the same frame, all spp, %.1f s, %d threads" % (n_b, nb, stride, dt, threads),
             "frame_ms_extrapolated": dt * 1e3 * nb / n_b,
@@ -195,6 +203,10 @@ def main():
     ap.add_argument("--shard-of", type=int, default=0, help="diagnosis on one GPU: render only ONE rank's share of an N-rank run (buckets r mod N, r = --shard-rank), no exchange")
     ap.add_argument("--shard-rank", type=int, default=0, help="with --shard-of N: whose share (tools/shard_balance.py measures every rank's)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the real multi-GPU run) or gloo (rehearsal: N ranks sharing GPU 0)")
+    ap.add_argument("--arith", default="exact", choices=["exact", "contracted"],
+                    help="exact (default): the reference's arithmetic everywhere, every pixel the oracle's bit for bit.  contracted: option fp_contract = 1 for the timed region "
+                    "(path tracing past a sample's first closest hit on kernels built with fused multiply-adds; colour within 1e-4 RMS).  The default run reports the "
+                    "contracted figures too, in a `contracted` object beside the exact line")
     ap.add_argument("--library-gather", action="store_true", help="with --backend gloo: still exchange through frayhip_gather_buckets (the library binds whatever RCCL "
                     "FRAYHIP_RCCL_LIBRARY names -- on a one-GPU box the test suite's loopback stand-in, since RCCL itself refuses two ranks on one device)")
     args = ap.parse_args()
@@ -235,6 +247,10 @@ def main():
     scene = open_scene(fray_amd, name, W, H, over)
     scene.beginRender()
     mode = abi.MODE_PRIMARY_ID if args.workload.endswith("_primary") else abi.MODE_RENDER
+    if args.arith == "contracted":
+        if not scene.settings.gi:
+            raise SystemExit("bench.py --arith contracted: only the path tracer has contracted kernels")
+        scene.set_option("fp_contract", 1)
 
     frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     ids = torch.zeros((H, W), dtype=torch.int32, device=dev) if mode == abi.MODE_PRIMARY_ID else None
@@ -395,6 +411,30 @@ def main():
         if ser_scene is not scene:
             ser_scene.close()
 
+    # The same frame with option "fp_contract" = 1 (north_star bounds shaded colour by 1e-4 RMS, only PRIMARY hit records by bits): timed like the region above,
+    # counted by its own instrumented pass, and kept for the parity figures of cpu_baseline below.  The default line stays the exact one.
+    contracted = None
+    exact_frame = frame
+    if rank == 0 and world == 1 and scene.settings.gi and mode == abi.MODE_RENDER and args.arith == "exact" and args.shard_of <= 1:
+        exact_frame = frame.clone()
+        scene.set_option("fp_contract", 1)
+        st_c = step(stats=True)
+        for _ in range(min(args.warmup, 2)):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        ms_c = (time.perf_counter() - t1) * 1e3 / args.steps
+        scene.set_option("fp_contract", 0)
+        rays_c = float(st_c["closest_rays"] + st_c["shadow_rays"])
+        contracted = {"option": "fp_contract = 1: k_pt_bounce after a sample's first closest hit and every k_pt_shadow launch run the kernels of render_contract.hip (-ffp-contract=fast, "
+                                "reciprocal / rsqrt with two refinement steps, plain-double sin / cos); primary hits and first bounces stay exact",
+                      "contracted_launches_per_frame": scene.get_option("contracted_launches"),
+                      "ms_per_step": ms_c, "value": rays_c / (ms_c * 1e-3) / 1e6, "unit": "Mrays/s", "rays_per_frame": rays_c, "steps": args.steps,
+                      "speedup_vs_exact": ms_per_step / ms_c, "frame": frame.clone()}
+
     if rank == 0:
         from tools.source_hash import source_hash
         src = source_hash()
@@ -426,6 +466,7 @@ def main():
             "data": "reference scene file scenes/%s (unchanged), RNG contract seed %d" % (name, args.seed),
             "config": {"workload": desc_text, "width": W, "height": H, "spp": scene.samples_per_pixel(),
                        "rays_per_frame": rays_total, "camera_samples_per_frame": float(counts[2]),
+                       "arith": args.arith,
                        "parallelism": "tiles%d" % world if world > 1 else ("rank %d's share of tiles%d, no exchange (diagnosis)" % (args.shard_rank, args.shard_of) if args.shard_of > 1 else "single-gpu"),
                        "frame_ms": ms_per_step, "msamples_per_s": float(counts[2]) / (ms_per_step * 1e-3) / 1e6,
                        # glossy fans drawn and traced ahead in the last timed frame (frayhip_scene_get_option; zero unless the scene has such fans and no sampling light)
@@ -506,8 +547,19 @@ def main():
                     out["roofline"]["counters_note"] = "%s is for source %s / %s: not this build" % (os.path.relpath(pmc_path, ROOT), pmc.get("source_hash"), pmc.get("workload"))
             except (KeyError, ValueError, OSError):
                 pass
+        cframe = contracted.pop("frame") if contracted else None
+        if contracted:
+            d = (cframe.double() - exact_frame.double())
+            contracted["vs_exact_frame"] = {"rms_per_channel": [float(v) for v in (d ** 2).mean(dim=(0, 1)).sqrt().cpu()], "max_abs": float(d.abs().max()),
+                                            "bit_identical_pixels": float((cframe == exact_frame).all(dim=2).float().mean())}
+            out["contracted"] = contracted
+            out["value_contracted"] = contracted["value"]
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(fray_amd, abi, wl, args.seed, gpu_frame=frame.cpu().numpy()) if mode == abi.MODE_RENDER else None
+            out["cpu_baseline"] = cpu_baseline(fray_amd, abi, wl, args.seed, gpu_frame=exact_frame.cpu().numpy(),
+                                               other_frames={"contracted": cframe.cpu().numpy()} if cframe is not None else None) if mode == abi.MODE_RENDER else None
+            if contracted and out["cpu_baseline"] and "other_frames_vs_oracle_on_the_sample" in out["cpu_baseline"]:
+                contracted["vs_oracle_on_the_sample"] = out["cpu_baseline"].pop("other_frames_vs_oracle_on_the_sample")["contracted"]
+                contracted["rms_per_channel"] = contracted["vs_oracle_on_the_sample"]["rms_per_channel"]
         print(json.dumps(out), flush=True)
     scene.close()
     if world > 1:

@@ -139,7 +139,9 @@ int bounce_grid(size_t n, bool alone)
 
 int seed_grid(size_t n)          // k_seed: many short threads
 {
-    static const long cap = getenv("FRAYHIP_SEED_BLOCKS") ? atol(getenv("FRAYHIP_SEED_BLOCKS")) : 32768;     // forest DOF 256: 155.2 ms at 2 048 blocks, 153.6 at 32 768 (a thread runs few chains and the last waves leave together)
+    // forest DOF 256: 155.2 ms at 2 048 blocks, 153.6 at 32 768 (a thread runs few chains and the last waves leave together).  FRAYHIP_SEED_BLOCKS is a
+    // development knob, read once per process and validated like the others: 1..65535, anything else keeps the default
+    static const long cap = [] { const char* e = getenv("FRAYHIP_SEED_BLOCKS"); const long v = e ? atol(e) : 0; return v >= 1 && v <= 65535 ? v : 32768L; }();
     size_t blocks = (n + 255) / 256;
     if (blocks > (size_t)cap) blocks = (size_t)cap;
     if (blocks < 1) blocks = 1;
@@ -184,12 +186,15 @@ size_t work_budget(frayhip_scene* sc)
 }
 
 // ensure_work for a plan made under work_budget(): FRAYHIP_OK, an error, or FRAYHIP_RETRY_SMALLER after halving the budget (the caller plans again).
-int ensure_work_or_shrink(frayhip_scene* sc, size_t bytes)
+// `canRetry`: the caller will plan again with the smaller budget (it is not pinned by frayhip_frame.spp_chunk and is not already at one sample per
+// batch); only then is the halved budget kept -- a failure the caller can do nothing about must not shrink every later frame's batches (it is
+// reported as FRAYHIP_E_NOMEM and the budget stays; option "pt_budget_effective_mib" reads what frames currently plan with).
+int ensure_work_or_shrink(frayhip_scene* sc, size_t bytes, bool canRetry)
 {
     const int rc = ensure_work(sc, bytes);
     if (rc != FRAYHIP_E_NOMEM) return rc;
     (void)hipGetLastError();
-    if (work_budget(sc) <= ((size_t)64 << 20)) return rc;          // already at the floor: give up with the allocation's message
+    if (!canRetry || work_budget(sc) <= ((size_t)64 << 20)) return rc;          // nothing to plan again, or already at the floor: give up with the allocation's message
     sc->ptBudgetEff = std::max<size_t>(sc->ptBudgetEff / 2, (size_t)64 << 20);
     return FRAYHIP_RETRY_SMALLER;
 }
@@ -385,7 +390,10 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         nodes[i].shader = n.shader;
         nodes[i].bumpTex = n.bump_tex;
         nodes[i].xfClass = i;
-        nodes[i].pad = 0;
+        {
+            static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z3[3] = {0, 0, 0};       // +0.0 everywhere: a -0.0 in the file's transform is not the identity
+            nodes[i].xfIdentity = (!memcmp(n.T.offset, Z3, sizeof Z3) && !memcmp(n.T.m, I9, sizeof I9) && !memcmp(n.T.invM, I9, sizeof I9)) ? 1 : 0;
+        }
         for (int j = 0; j < i; j++)
             if (!memcmp(d.nodes[j].T.offset, n.T.offset, sizeof n.T.offset) && !memcmp(d.nodes[j].T.invM, n.T.invM, sizeof n.T.invM) &&
                 !memcmp(d.nodes[j].T.m, n.T.m, sizeof n.T.m)) {
@@ -580,7 +588,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     for (int i = 0; i < d.n_nodes; i++) {
         DNode& N = nodes[i];
         DNodeX& X = nodesX[i];
-        N.tlTris = 0; N.tlCulling = 0; N.pad = 0; N.tlPtr = nullptr; N.boxMax = 0;
+        N.tlTris = 0; N.tlCulling = 0; N.tlPtr = nullptr; N.boxMax = 0;
         for (int k = 0; k < 3; k++) N.bmin[k] = N.bmax[k] = X.bminE[k] = X.bmaxE[k] = 0;
         if (N.geomKind == FRAYHIP_GEOM_MESH && !meshes[N.geomIndex].hasKd) {
             const DMesh& M = meshes[N.geomIndex];
@@ -657,6 +665,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     // profiling aids: the same knobs as frayhip_scene_set_option, preset from the environment
     if (const char* e = getenv("FRAYHIP_PT_LANES")) { long v = atol(e); if (v >= 1 && v <= FRAY_PT_LANES) sc->ptLanes = (int)v; }
     if (const char* e = getenv("FRAYHIP_SPECULATE_FANS")) sc->speculateFans = atol(e) != 0;
+    if (const char* e = getenv("FRAYHIP_FP_CONTRACT")) sc->fpContract = atol(e) == 1;
     if (const char* e = getenv("FRAYHIP_PT_BUDGET_MIB")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) { sc->ptBudgetBytes = (size_t)v << 20; sc->ptBudgetEff = 0; } }
     *out = sc;
     return FRAYHIP_OK;
@@ -669,6 +678,9 @@ int frayhip_scene_get_option(frayhip_scene* s, const char* name, int64_t* value)
     if (n == "pt_lanes") *value = s->ptLanes;
     else if (n == "pt_budget_mib") *value = (int64_t)(s->ptBudgetBytes >> 20);
     else if (n == "speculate_fans") *value = s->speculateFans ? 1 : 0;
+    else if (n == "fp_contract") *value = s->fpContract ? 1 : 0;
+    else if (n == "contracted_launches") *value = s->lastContracted;
+    else if (n == "pt_budget_effective_mib") *value = (int64_t)(frayhip_detail::work_budget(s) >> 20);
     else if (n == "fans_filed") *value = s->lastFans[0];
     else if (n == "fan_children") *value = s->lastFans[1];
     else if (n == "fan_children_looked_up") *value = s->lastFans[2];
@@ -691,6 +703,9 @@ int frayhip_scene_set_option(frayhip_scene* s, const char* name, int64_t value)
     } else if (n == "speculate_fans") {
         if (value != 0 && value != 1) { set_error("frayhip_scene_set_option: speculate_fans must be 0 or 1"); return FRAYHIP_E_ARG; }
         s->speculateFans = value != 0;
+    } else if (n == "fp_contract") {
+        if (value != 0 && value != 1) { set_error("frayhip_scene_set_option: fp_contract must be 0 or 1"); return FRAYHIP_E_ARG; }
+        s->fpContract = value != 0;
     } else {
         set_error("frayhip_scene_set_option: unknown option " + n);
         return FRAYHIP_E_ARG;

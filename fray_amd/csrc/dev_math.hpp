@@ -50,6 +50,44 @@ FD void stamp_begin()
 #define STAMP(k) do { } while (0)
 #endif
 
+// Division, reciprocal, square root.  FRAY_ARITH == 0 (every translation unit but render_contract.hip): IEEE, the reference's.  FRAY_ARITH == 1 (the
+// path tracer's kernels for rays after a sample's first closest hit, option "fp_contract"): the hardware's reciprocal / reciprocal square root with the two
+// refinement steps the IEEE expansions start with, but without their scaling, fix-up and final correction -- results within an ulp or two, 5 and 9
+// instructions instead of 13 and 17.  (Operands here are lengths, determinants and direction components: never subnormal, never huge.)
+#ifndef FRAY_ARITH
+#define FRAY_ARITH 0
+#endif
+#if FRAY_ARITH && defined(__HIP_DEVICE_COMPILE__)
+FD double fray_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+FD double fray_div(double a, double b) { return a * fray_rcp(b); }
+FD double fray_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-x * y, y, 1.0);          // 1 - x y^2
+    y = __builtin_fma(0.5 * y, e, y);
+    e = __builtin_fma(-x * y, y, 1.0);
+    return __builtin_fma(0.5 * y, e, y);
+}
+FD double fray_sqrt(double x)
+{
+    if (!(x > 0.0)) return x < 0.0 ? __builtin_nan("") : x;          // +-0 (a degenerate segment) stays what sqrt makes of it
+    const double y = fray_rsqrt(x);
+    const double g = x * y;
+    return __builtin_fma(__builtin_fma(-g, g, x), 0.5 * y, g);       // one correction of x y towards sqrt(x)
+}
+#else
+FD double fray_rcp(double x) { return 1.0 / x; }
+FD double fray_div(double a, double b) { return a / b; }
+FD double fray_sqrt(double x) { return sqrt(x); }
+#endif
+
 struct V3 { double x, y, z; };
 struct C3 { float r, g, b; };
 
@@ -66,8 +104,12 @@ FD V3 operator*(double m, V3 a) { return v3(a.x * m, a.y * m, a.z * m); }
 FD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 FD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 FD double lengthSqr(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
-FD double length(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+FD double length(V3 a) { return fray_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+#if FRAY_ARITH && defined(__HIP_DEVICE_COMPILE__)
+FD V3 normalized(V3 a) { return a * fray_rsqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+#else
 FD V3 normalized(V3 a) { double m = 1.0 / length(a); return a * m; }   // vector.h:81-85
+#endif
 FD double comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 FD V3 faceforward(V3 d, V3 n) { return dot(d, n) < 0 ? n : -n; }        // vector.h:169-175
 FD V3 reflect(V3 i, V3 n) { return i + 2 * dot(-i, n) * n; }            // vector.h:178-181
@@ -76,7 +118,7 @@ FD V3 refract(V3 i, V3 n, double ior)                                   // vecto
     double NdotI = dot(i, n);
     double k = 1 - (ior * ior) * (1 - NdotI * NdotI);
     if (k < 0.0) return v3(0, 0, 0);
-    return normalized(ior * i - (ior * NdotI + sqrt(k)) * n);
+    return normalized(ior * i - (ior * NdotI + fray_sqrt(k)) * n);
 }
 FD void orthonormalSystem(V3 a, V3& b, V3& c)                           // vector.h:197-213
 {

@@ -50,7 +50,7 @@ struct DNode {
     // copy of what its root box test and triangle loop read, so neither needs a second dependent load through DMesh:
     int32_t tlTris;       // number of triangles; 0 for every other geometry
     int32_t tlCulling;
-    int32_t pad;
+    int32_t xfIdentity;   // offset = 0 and m = invM = I, bit for bit: the local ray is the world ray (node_intersect)
     double bmin[3], bmax[3];
     const FRAY_RO DTri* tlPtr;
     double boxMax;        // max |coordinate| of bmin / bmax (margins of the certified box test, dev_boxcert.hpp)

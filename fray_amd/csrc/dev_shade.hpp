@@ -217,7 +217,7 @@ FD void light_nth_sample(const FRAY_RO DLight& L, int idx, V3 shadePos, G& tab, 
     if (sp.y > 0) {
         color = c3(0, 0, 0);
     } else {
-        float cosWeight = float(dot(v3(0, -1, 0), sp) / length(sp));
+        float cosWeight = float(fray_div(dot(v3(0, -1, 0), sp), length(sp)));
         color = ldc(L.color) * L.power * (float)L.area * cosWeight;
     }
     samplePos = mulM(pointOnLight, L.T.m) + ld3(L.T.off);
@@ -226,7 +226,7 @@ FD double light_solid_angle(const FRAY_RO DLight& L, V3 ip)
 {
     if (L.kind == 0) return 0;
     double q = lengthSqr(ip - ld3(L.center));
-    return L.area / (1.0 < q ? q : 1.0);   // std::max(1.0, q)
+    return fray_div(L.area, 1.0 < q ? q : 1.0);   // std::max(1.0, q)
 }
 
 // ---- Whitted: Lambert::shade / Phong::shade (shading.cpp:48-80, 101-144) ---------------------------
@@ -287,7 +287,7 @@ FD C3 brdf_eval(const FRAY_RO DShader& sh, const HitInfo& x, V3 w_out)
     if (sh.kind == 1) {   // Lambert::eval, shading.cpp:82-86
         double dd = dot(x.norm, w_out);
         float cosTerm = (float)(0.0 < dd ? dd : 0.0);
-        return ldc(sh.color) * (float)(cosTerm / FRAY_PI);
+        return ldc(sh.color) * (float)fray_div(cosTerm, FRAY_PI);
     }
     if (sh.kind == 3 || sh.kind == 4) return c3(0, 0, 0);   // Reflection / Refraction::eval
     return c3(1, 0, 0);                                     // Shader::eval default, shading.h:124-127
@@ -308,7 +308,7 @@ FD void spawn_ray(const FRAY_RO DShader& sh, const HitInfo& x, const PathRay& w_
         w_out.flags |= RF_DIFFUSE;
         double dd = dot(x.norm, w_out.d);
         float cosTerm = (float)(0.0 < dd ? dd : 0.0);
-        brdf = ldc(sh.color) * (float)(cosTerm / FRAY_PI);
+        brdf = ldc(sh.color) * (float)fray_div(cosTerm, FRAY_PI);
         pdf = (float)(1 / (2 * FRAY_PI));
         return;
     }
@@ -370,7 +370,7 @@ FD bool nee_prepare(const DScene& S, V3 rayDir, const HitInfo& info, C3 pm, cons
     V3 w_out = normalized(pointOnLight - x);
     C3 brdfAtPoint = brdf_eval(sh, info, w_out);
     if (intensity(brdfAtPoint) == 0) { contrib = c3(0, 0, 0); return true; }
-    float probHitLightArea = (float)(1.0f / solidAngle);
+    float probHitLightArea = (float)fray_rcp(solidAngle);
     float probPickThisLight = S.probPickLight;
     float chooseLightProb = probHitLightArea * probPickThisLight;
     contrib = Le * pm * brdfAtPoint / chooseLightProb;

@@ -171,7 +171,7 @@ FD bool tri_test(const FRAY_RO DTri* T, int culling, V3 s, V3 d, double& best, d
     double Dcr = dot(N, D);
     ok &= lanes(!(fabs(Dcr) < 1e-12));
     if (!ok) return false;                  // wave-uniform: every lane culled this triangle
-    double rDcr = 1 / Dcr;
+    double rDcr = fray_rcp(Dcr);
     V3 H = s - A;
     double gamma = dot(N, H) * rDcr;
     ok &= lanes(!(gamma < 0)) & lanes(!(gamma > best));
@@ -197,7 +197,7 @@ FD void tri_bary(const FRAY_RO DTri* T, V3 s, V3 d, double& l2, double& l3)
 {
     const V3 N = ld3(T->N), A = ld3(T->A), AC = ld3(T->AC), AB = ld3(T->AB);
     const V3 D = -d;
-    const double rDcr = 1 / dot(N, D);
+    const double rDcr = fray_rcp(dot(N, D));
     const V3 H = s - A;
     l2 = dot(cross(H, AC), D) * rDcr;
     l3 = dot(cross(AB, H), D) * rDcr;
@@ -208,9 +208,9 @@ FD void tri_bary(const FRAY_RO DTri* T, V3 s, V3 d, double& l2, double& l3)
 FD V3 ray_rdir(V3 d)
 {
     V3 rd;
-    rd.x = fabs(d.x) > 1e-12 ? 1.0 / d.x : 1e12;
-    rd.y = fabs(d.y) > 1e-12 ? 1.0 / d.y : 1e12;
-    rd.z = fabs(d.z) > 1e-12 ? 1.0 / d.z : 1e12;
+    rd.x = fabs(d.x) > 1e-12 ? fray_rcp(d.x) : 1e12;
+    rd.y = fabs(d.y) > 1e-12 ? fray_rcp(d.y) : 1e12;
+    rd.z = fabs(d.z) > 1e-12 ? fray_rcp(d.z) : 1e12;
     return rd;
 }
 template <int ST>
@@ -469,7 +469,7 @@ FD bool cube_intersect(const FRAY_RO DCube& Cb, V3 s, V3 d, GHit& h)   // Cube::
         const double st = comp(s, ax), dr = comp(d, ax);
         const double target = (side & 1) ? comp(O, ax) + hs : comp(O, ax) - hs;
         if (fabs(dr) < 1e-9) continue;
-        double mult = (target - st) / dr;
+        double mult = fray_div(target - st, dr);
         if (mult < 0) continue;
         V3 ip = s + d * mult;
         if (ip.x < O.x - hs - 1e-6 || ip.x > O.x + hs + 1e-6) continue;
@@ -491,7 +491,7 @@ FD bool prim_intersect(const DScene& S, int kind, int index, V3 s, V3 d, V3 rd, 
         const FRAY_RO DPlane& P = S.planes[index];
         if (s.y > P.height && d.y >= 0) return false;
         if (s.y < P.height && d.y <= 0) return false;
-        double scaling = fabs(s.y - P.height) / fabs(d.y);
+        double scaling = fray_div(fabs(s.y - P.height), fabs(d.y));
         V3 ip = s + d * scaling;
         if (fabs(ip.x) > P.limit) return false;
         if (fabs(ip.z) > P.limit) return false;
@@ -507,7 +507,7 @@ FD bool prim_intersect(const DScene& S, int kind, int index, V3 s, V3 d, V3 rd, 
         double C = lengthSqr(H) - Sp.R * Sp.R;
         double Disc = B * B - 4 * 1 * C;
         if (Disc < 0) return false;
-        double sq = sqrt(Disc);
+        double sq = fray_sqrt(Disc);
         double p1 = (-B + sq) / (2 * 1.0), p2 = (-B - sq) / (2 * 1.0);
         double smaller = p2 < p1 ? p2 : p1, larger = p1 < p2 ? p2 : p1;
         if (larger < 0) return false;
@@ -656,7 +656,7 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, L
         if (ls.y < P.height && ld.y <= 0) return false;
         double travelByY = fabs(ls.y - P.height);
         double unitTravel = fabs(ld.y);
-        double scaling = travelByY / unitTravel;
+        double scaling = fray_div(travelByY, unitTravel);
         V3 ip = ls + ld * scaling;
         if (fabs(ip.x) > P.limit) return false;
         if (fabs(ip.z) > P.limit) return false;
@@ -673,7 +673,7 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, L
         double C = lengthSqr(H) - Sp.R * Sp.R;
         double Disc = B * B - 4 * A * C;
         if (Disc < 0) return false;
-        double sqrtDisc = sqrt(Disc);
+        double sqrtDisc = fray_sqrt(Disc);
         double p1 = (-B + sqrtDisc) / (2 * A);
         double p2 = (-B - sqrtDisc) / (2 * A);
         double smaller = p2 < p1 ? p2 : p1;   // std::min(p1, p2)
@@ -751,8 +751,25 @@ FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double&
     bump<ST>(c.node);
     const FRAY_RO DNode& N = S.nodes[i];
     if (N.xfClass != lr.cls) {
-        lr.s = mulM(o - ld3(N.T.off), N.T.inv);
-        lr.d = normalized(mulM(d, N.T.inv));
+        // An untransformed node (offset 0, m = invM = I, bit for bit: cornell_box's seven meshes): v * I is v.x * 1 + v.y * 0 + v.z * 0 = v.x exactly whenever
+        // v.x is not a zero (then the sum's sign of zero would depend on the other components), so the two 15-operation products are skipped unless some lane
+        // of the wave holds an exact zero; the normalisation is the reference's.
+#if FRAY_ARITH
+        // (relaxed arithmetic: the directions the path tracer makes are unit vectors to an ulp: no second normalisation, no zero check)
+        if (N.xfIdentity) {
+            lr.s = o;
+            lr.d = d;
+        } else {
+#else
+        const bool zeros = o.x == 0 || o.y == 0 || o.z == 0 || d.x == 0 || d.y == 0 || d.z == 0;
+        if (N.xfIdentity && !__any(zeros)) {
+            lr.s = o;
+            lr.d = normalized(d);
+        } else {
+#endif
+            lr.s = mulM(o - ld3(N.T.off), N.T.inv);
+            lr.d = normalized(mulM(d, N.T.inv));
+        }
         lr.cls = N.xfClass;
         lr.haveRd = false;
     }
@@ -762,7 +779,12 @@ FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double&
     STAMP(5);             // whatever geom_intersect did not stamp itself: planes, spheres, the KD walk
     if (!hit) return false;
     if constexpr ((ST & 2) != 0) { if (iplOut) *iplOut = ipl; }
-    V3 ipw = mulM(ipl, N.T.m) + ld3(N.T.off);
+    // (an untransformed node: ipl * I + 0 is ipl up to the sign of a zero, which the squares below do not see)
+#if FRAY_ARITH
+    // (relaxed arithmetic: along a unit direction in world space the ray parameter IS the distance -- planes, spheres, triangles; a Cube / CsgOp reports a length already)
+    if (N.xfIdentity) { dist = t; STAMP(6); return true; }
+#endif
+    V3 ipw = N.xfIdentity ? ipl : mulM(ipl, N.T.m) + ld3(N.T.off);
     dist = length(o - ipw);
     STAMP(6);
     return true;
@@ -780,7 +802,7 @@ FD bool light_intersect(const FRAY_RO DLight& L, V3 o, V3 d, double& dist, Cnt& 
     if (ldir.y <= 0) return false;
     double travelByY = fabs(ls.y);
     double unitTravel = fabs(ldir.y);
-    double scaling = travelByY / unitTravel;
+    double scaling = fray_div(travelByY, unitTravel);
     V3 ip = ls + ldir * scaling;
     if (fabs(ip.x) > 0.5 || fabs(ip.z) > 0.5) return false;
     ip = mulM(ip, L.T.m) + ld3(L.T.off);
@@ -842,7 +864,7 @@ FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c)
     // main.cpp:66-70 takes distance(a, b) = length(a - b) and then normalises b - a, i.e. divides by length(b - a): the two lengths are the same
     // bits (a - b is exactly -(b - a), and squares do not see the sign), so one square root serves both
     const double maxDist = length(d);
-    d = d * (1.0 / maxDist);
+    d = d * fray_rcp(maxDist);
     const int nn = S.nNodes;
     LocalRay lr;
     lr.cls = -1;

@@ -75,6 +75,34 @@ FRAY_TRIG_FN void fray_sincos_dd(double x, DD& sn, DD& cs)
     }
 }
 
+#if defined(FRAY_ARITH) && FRAY_ARITH && defined(__HIP_DEVICE_COMPILE__)
+// The kernels for rays after a sample's first closest hit under option "fp_contract" (render_contract.hip): their directions need no correct rounding --
+// a last place of a sampled direction is 1e-16 of a colour -- so the same reduction and table run in plain double (an ulp or two), a sixth of the instructions.
+FRAY_TRIG_FN void fray_sincos(double x, double* s, double* c)
+{
+    const double mf = __builtin_rint(x * FRAY_128OPI);
+    const int m = (int)mf;
+    const double t = __builtin_fma(-mf, FRAY_PIO128_2, __builtin_fma(-mf, FRAY_PIO128_1, x));
+    const double u = t * t;
+    const double st = __builtin_fma(t * u, -0x1.5555555555555p-3 + u * (0x1.1111111111111p-7 + u * -0x1.a01a01a01a01ap-13), t);      // sin t
+    const double cm = u * (-0.5 + u * (0x1.5555555555555p-5 + u * -0x1.6c16c16c16c17p-10));                                         // cos t - 1
+    const int q = (m >> 6) & 3, j = m & 63;
+    double S = kTrigTable[j][0], C = kTrigTable[j][2];
+    if (q & 1) { const double a0 = S; S = C; C = -a0; }
+    if (q & 2) { S = -S; C = -C; }
+    *s = S + __builtin_fma(S, cm, C * st);
+    *c = C + __builtin_fma(C, cm, -S * st);
+}
+// sin and cos of acos(v): v itself and sqrt(1 - v^2)
+FRAY_TRIG_FN void fray_acos_sincos(double v, double* s, double* c)
+{
+    *c = v;
+    *s = fray_sqrt(__builtin_fma(-v, v, 1.0));
+}
+#define FRAY_TRIG_RELAXED 1
+#endif
+
+#ifndef FRAY_TRIG_RELAXED
 FRAY_TRIG_FN void fray_sincos(double x, double* s, double* c)
 {
     if (!(x >= 0.0 && x <= 6.2918)) { FRAY_TRIG_LIBM_SINCOS(x, s, c); return; }      // outside the sampler's range (never in a render): the library's
@@ -108,3 +136,4 @@ FRAY_TRIG_FN void fray_acos_sincos(double v, double* s, double* c)
     *s = sn.h + (sn.l + cs.h * dy);                            // sin(y0 + dy) = sin y0 + cos y0 dy  (dy^2 ~ 2^-104)
     *c = cs.h + (cs.l - sn.h * dy);
 }
+#endif

@@ -1058,7 +1058,13 @@ struct LongRng { uint32_t* cols; uint32_t nPaths; DFrame F; int nItems, s0; };
 // reading them from a queue -- no 92-byte path record written and read back per camera sample, one launch less per batch.
 struct FirstArgs { DCamera C; DFrame F; int nItems, s0; uint32_t n; const uint32_t* x397; unsigned short* termCount; };
 struct BounceArgs { DScene S; PathQueue Qin, Qout; ShadowQueue SQ; QMetaRO metaIn; QMeta* metaOut; QMeta* metaShadow; TermBuf TB; StereoBuf SB; LongRng LR; DStats* st; FirstArgs FA; };
-template <int ST, bool LONG, bool FIRST = false>
+// ARITH: how the translation unit was compiled -- 0 = the reference's arithmetic (-ffp-contract=off: every hit record and every colour is the CPU reference build's, bit
+// for bit), 1 = -ffp-contract=fast (render_contract.hip: multiply-add pairs fused; only for rays AFTER a sample's first closest hit, i.e. colour within
+// north_star's 1e-4 RMS, option "fp_contract").  The parameter only names the kernel apart in profiles; the code is the same source.
+#ifndef FRAY_ARITH
+#define FRAY_ARITH 0
+#endif
+template <int ST, bool LONG, bool FIRST = false, int ARITH = FRAY_ARITH>
 static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOUNCE_WAVES : FRAY_BOUNCE_WAVES_NOKD)) void k_pt_bounce(BounceArgs A)
 {
     static_assert(!(LONG && FIRST), "long generators start from k_pt_init");
@@ -1172,7 +1178,7 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
 // visible() for every queued next-event segment (main.cpp:64-80, 143-144): the sample's term of this bounce is the
 // segment's radiance if it is unobstructed, black otherwise.
 struct ShadowArgs { DScene S; ShadowQueue SQ; QMetaRO meta; TermBuf TB; DStats* st; };
-template <int ST>
+template <int ST, int ARITH = FRAY_ARITH>
 static __global__ __launch_bounds__(256, anyhit_waves(ST)) void k_pt_shadow(ShadowArgs A)
 {
     Cnt c = zero_cnt();
@@ -1216,6 +1222,12 @@ static __global__ __launch_bounds__(256, anyhit_waves(ST)) void k_pt_shadow(Shad
 #endif
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
+}
+
+// The same two kernels compiled with fused multiply-adds (render_contract.hip, one translation unit per flag word like render_variant.hip)
+namespace frayhip_detail {
+template <int ST> void launch_bounce_contracted(int grid, hipStream_t stream, const BounceArgs& A);
+template <int ST> void launch_shadow_contracted(int grid, hipStream_t stream, const ShadowArgs& A);
 }
 
 // A camera sample's radiance from its terms, innermost first (TermBuf): result = term[n-1]; result = term[k] + result for k = n-2 .. 0.

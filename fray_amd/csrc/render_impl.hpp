@@ -82,6 +82,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
     DCursors* cursors = (DCursors*)((unsigned char*)sc->d_stats + kCursorOffset);
     HIP_TRY(hipEventRecord(sc->evA, stream));
     size_t nTraceEvents = 0, nShadowEvents = 0;
+    long long nContracted = 0;          // launches of this frame that ran a kernel of render_contract.hip (option "fp_contract")
     const unsigned long long* fanTotals = nullptr;          // device: the speculative fans' counters summed over the frame's batches
 
     if (f->mode == FRAYHIP_MODE_PRIMARY_ID) {
@@ -120,10 +121,11 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     if (chunk > spp) chunk = spp;
                     while (chunk > 1 && (size_t)nItems * chunk * (size_t)std::max(fan, 1) >= ((size_t)1 << 31)) chunk /= 2;
                     const size_t slots = (size_t)nItems * chunk, kids = slots * (size_t)fan;
+                    const bool canRetry = f->spp_chunk <= 0 && chunk > 1;
                     const int rc = ensure_work_or_shrink(sc, colBytes + r256((size_t)nItems * 12) + r256(slots * 12) + r256(slots * 4) +
-                                                             (fan > 0 ? 256 + 2 * r256(slots * 4) + 3 * r256(slots * 8) + r256(kids * 4) + 3 * r256(kids * 8) + 3 * r256(kids * 4) + 2 * r256(kids) : 0));
-                    if (rc == FRAYHIP_RETRY_SMALLER && f->spp_chunk <= 0 && chunk > 1) continue;
-                    if (rc) { if (rc == FRAYHIP_RETRY_SMALLER) return FRAYHIP_E_NOMEM; return rc; }
+                                                             (fan > 0 ? 256 + 2 * r256(slots * 4) + 3 * r256(slots * 8) + r256(kids * 4) + 3 * r256(kids * 8) + 3 * r256(kids * 4) + 2 * r256(kids) : 0), canRetry);
+                    if (rc == FRAYHIP_RETRY_SMALLER) continue;
+                    if (rc) return rc;
                     break;
                 }
                 unsigned char* p = (unsigned char*)sc->d_work;
@@ -195,9 +197,9 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     slots = (size_t)nItems * chunk; N = slots * eyes; NT = N * (size_t)T;
                     const size_t bytes = colBytes + r256((size_t)nItems * 12) + r256(N * 12) + 3 * r256(N * 8) + r256(N) + 3 * r256(NT * 8) + 3 * r256(NT * 4) + r256(NT) +
                                          2 * r256(slots * 12) + r256(slots * 4) + 4096;
-                    const int rc = ensure_work_or_shrink(sc, bytes);
-                    if (rc == FRAYHIP_RETRY_SMALLER && f->spp_chunk <= 0 && chunk > 1) continue;
-                    if (rc) { if (rc == FRAYHIP_RETRY_SMALLER) return FRAYHIP_E_NOMEM; return rc; }
+                    const int rc = ensure_work_or_shrink(sc, bytes, f->spp_chunk <= 0 && chunk > 1);
+                    if (rc == FRAYHIP_RETRY_SMALLER) continue;
+                    if (rc) return rc;
                     break;
                 }
                 unsigned char* p = (unsigned char*)sc->d_work;
@@ -272,9 +274,9 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 nQueue = nPaths + (size_t)bounce_grid(nPaths, (ST & 2) != 0) * 4 * 128;
                 laneBytes = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + nPaths * 4 + 4096 + nPaths * termBytes + 512 + (longRng ? nPaths * 2 * 624 * sizeof(uint32_t) + 256 : 0) +
                             (stereo ? nPaths * (12 + 6 * 8 + 6 * 4) + 16 * 256 : 0);
-                const int rc = ensure_work_or_shrink(sc, (size_t)nLanes * laneBytes + (size_t)nItems * 12 + 4096);
-                if (rc == FRAYHIP_RETRY_SMALLER && f->spp_chunk <= 0 && (chunk > 1 || nLanes > 1)) { if (chunk == 1 && maxLanes > 1) maxLanes--; continue; }
-                if (rc) { if (rc == FRAYHIP_RETRY_SMALLER) return FRAYHIP_E_NOMEM; return rc; }
+                const int rc = ensure_work_or_shrink(sc, (size_t)nLanes * laneBytes + (size_t)nItems * 12 + 4096, f->spp_chunk <= 0 && (chunk > 1 || nLanes > 1));
+                if (rc == FRAYHIP_RETRY_SMALLER) { if (chunk == 1 && maxLanes > 1) maxLanes--; continue; }
+                if (rc) return rc;
                 break;
             }
             struct Lane {
@@ -346,14 +348,26 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                         const TermBuf TB{L.terms, L.termCount, (uint32_t)nPaths, b};
                         const FirstArgs FA{C, F, nItems, s0, (uint32_t)((size_t)nItems * cn), L.x397, L.termCount};
                         const BounceArgs BA{S, L.Q[b & 1], L.Q[(b + 1) & 1], L.SQ, mIn, L.meta + ((b + 1) & 1), L.meta + 2, TB, save, LR, sc->d_stats, FA};
-                        if (longRng) hipLaunchKernelGGL((k_pt_bounce<ST, true>), dim3(grid), dim3(256), 0, ls, BA);
+                        // option "fp_contract": bounces after a sample's first closest hit (and every visibility query) are colour, bounded by RMS and not by
+                        // bits -- they run the kernels compiled with fused multiply-adds (render_contract.hip; not built for the Cube / CSG variants, which
+                        // measured slower with it)
+                        bool contractedLaunch = false;
+                        if constexpr (!(ST & 2)) {
+                            if (sc->fpContract && !longRng && b > 0) { launch_bounce_contracted<ST>(grid, ls, BA); contractedLaunch = true; nContracted++; }
+                        }
+                        if (contractedLaunch) {}
+                        else if (longRng) hipLaunchKernelGGL((k_pt_bounce<ST, true>), dim3(grid), dim3(256), 0, ls, BA);
                         else if (fused && b == 0) hipLaunchKernelGGL((k_pt_bounce<ST, false, true>), dim3(grid), dim3(256), 0, ls, BA);
                         else hipLaunchKernelGGL((k_pt_bounce<ST, false>), dim3(grid), dim3(256), 0, ls, BA);
                         HIP_TRY(hipEventRecord(eb, ls));
                         nTraceEvents += 2;
                         hipLaunchKernelGGL(k_scan, dim3(2), dim3(1024), 0, ls, L.meta + ((b + 1) & 1), L.meta + 2);
                         HIP_TRY(hipEventRecord(ec, ls));
-                        hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid), dim3(256), 0, ls, ShadowArgs{S, L.SQ, mSh, TB, sc->d_stats + 1});
+                        bool contractedShadow = false;
+                        if constexpr (!(ST & 2)) {
+                            if (sc->fpContract) { launch_shadow_contracted<ST>(grid, ls, ShadowArgs{S, L.SQ, mSh, TB, sc->d_stats + 1}); contractedShadow = true; nContracted++; }
+                        }
+                        if (!contractedShadow) hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(grid), dim3(256), 0, ls, ShadowArgs{S, L.SQ, mSh, TB, sc->d_stats + 1});
                         HIP_TRY(hipEventRecord(ed, ls));
                         nShadowEvents += 2;
                     }
@@ -385,6 +399,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
         unsigned long long ft[4] = {0, 0, 0, 0};
         if (fanTotals) HIP_TRY(hipMemcpy(ft, fanTotals, sizeof ft, hipMemcpyDeviceToHost));
         for (int q = 0; q < 4; q++) sc->lastFans[q] = (long long)ft[q];
+        sc->lastContracted = nContracted;
     }
 #ifdef FRAY_LEAFSTAT
     {

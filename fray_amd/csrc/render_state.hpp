@@ -49,6 +49,8 @@ struct frayhip_scene {
     bool whittedNeedsRecursion = false;
     int specFanMax = 0;               // > 0: the largest numSamples of a glossy Refl shader, in a scene whose lights draw no random numbers (speculative glossy fans, dev_whitted.hpp)
     bool speculateFans = true;        // option "speculate_fans"
+    bool fpContract = false;          // option "fp_contract": path tracing past a sample's first closest hit on the kernels built with fused multiply-adds (render_contract.hip)
+    long long lastContracted = 0;     // the last frame's launches of contracted kernels (frayhip_scene_get_option "contracted_launches")
     long long lastFans[4] = {0, 0, 0, 0};   // the last frame's fans filed, children traced ahead, children looked up, fans given up part of the way (frayhip_scene_get_option)
     int lightSampleCount = 0;         // sum over lights of Light::getNumSamples(): segments a Lambert / Phong hit queues (wavefront Whitted)
     bool extGeometry = false;         // Cube / CSG nodes present
@@ -83,7 +85,7 @@ DCamera camera_begin_frame(const frayhip_camera& c, int W, int H);
 int persistent_grid(size_t n, int wavesPerSimd);
 size_t work_budget(frayhip_scene* sc);
 enum { FRAYHIP_RETRY_SMALLER = 1 };      // internal: ensure_work_or_shrink halved the budget, plan the frame again
-int ensure_work_or_shrink(frayhip_scene* sc, size_t bytes);
+int ensure_work_or_shrink(frayhip_scene* sc, size_t bytes, bool canRetry);
 int bounce_grid(size_t n, bool alone);
 int grid_for(size_t n);
 int seed_grid(size_t n);

@@ -111,7 +111,8 @@ class Scene:
             self._dev = C.c_void_p()
 
     def set_option(self, name, value):
-        """frayhip_scene_set_option: "pt_lanes" (1..4 batches in flight), "pt_budget_mib" (queue memory), "speculate_fans" (0 / 1)."""
+        """frayhip_scene_set_option: "pt_lanes" (1..4 batches in flight), "pt_budget_mib" (queue memory), "speculate_fans" (0 / 1), "fp_contract" (0 / 1: relaxed arithmetic
+        for path-traced rays after a sample's first closest hit, include/frayhip.h)."""
         self._need_dev()
         _check(lib.frayhip_scene_set_option(self._dev, name.encode(), int(value)))
         return self

@@ -184,7 +184,10 @@ def test_build_recipe_keeps_what_correctness_depends_on(fray):
     flags = [l for l in mk.splitlines() if l.startswith("HIPFLAGS")]
     assert flags and "-mllvm -wwm-regalloc=basic" in flags[0]
     reports = sorted(glob.glob(os.path.join(ROOT, "fray_amd", "csrc", "variant*.resources.txt")))
-    assert len(reports) == 8, reports
+    # eight flag words of render_variant.hip + six of render_contract.hip (option "fp_contract": every flag word but the two Cube / CSG ones)
+    assert len(reports) == 14 and sum(os.path.basename(r).startswith("variantC") for r in reports) == 6, reports
+    # the contracted kernels are built with fused multiply-adds and NOTHING ELSE is: one rule of the Makefile carries the flag
+    assert mk.count("-ffp-contract=fast") == 1 and "variantC%.o" in mk.split("-ffp-contract=fast")[0].splitlines()[-2]
     for r in reports:
         names = re.findall(r"Function Name: (\S+)", open(r).read())
         assert names, r

@@ -4,22 +4,33 @@
 #include <stdint.h>
 #include "dev_scene.hpp"   // FRAY_RO
 
+// One path of the queue: 96 bytes = six 16-byte loads per lane, the ray in the first three (what the closest-hit search needs), the rest of the
+// state in the last three (fetched after the search).  Records, not one array per field: a wave that works through its share in the order of the
+// coherence sort (kernels.hpp sort_share) reads entries in an order of its own, and a 16-byte-per-lane load costs the L1 the same 64 accesses wherever
+// its lanes point, while seventeen gathered field arrays cost seventeen times 64 and as many cache lines (measured with the arrays: bounce kernel
+// -11 % instructions, +20 % time, 3.3 x the L2 read requests).
+struct alignas(16) PathRec {
+    double o[3], d[3];
+    float pm[3];                          // pathMultiplier
+    uint32_t slot;                        // sample-major slot in the batch
+    uint32_t depthFlags;                  // depth | flags << 16; FRAY_DEAD: no path (a slot of a ragged edge bucket outside the frame)
+    uint32_t rnd[3], tab[3];              // the two generators' cursors {j, x[j], x[j + 397]}
+    uint32_t pad;
+};
 struct PathQueue {
-    double* ox; double* oy; double* oz;
-    double* dx; double* dy; double* dz;
-    float* tr; float* tg; float* tb;      // pathMultiplier
-    uint32_t* slot;                       // sample-major slot in the batch
-    uint32_t* depthFlags;                 // depth | flags << 16
-    uint32_t* rndJ; uint32_t* rndA; uint32_t* rndB;
-    uint32_t* tabJ; uint32_t* tabA; uint32_t* tabB;
+    PathRec* rec;
+    unsigned char* cls;                   // the ray's class (kernels.hpp ray_sort_class): all the coherence sort reads of an entry
 };
 
-// Shadow (next-event) queue: segment a->b, the radiance to add if it is unobstructed, the sample slot.
+// Shadow (next-event) queue: segment a->b, the radiance to add if it is unobstructed, the sample slot: 64 bytes.
+struct alignas(16) ShadowRec {
+    double a[3], b[3];
+    float c[3];
+    uint32_t slot;
+};
 struct ShadowQueue {
-    double* ax; double* ay; double* az;
-    double* bx; double* by; double* bz;
-    float* cr; float* cg; float* cb;
-    uint32_t* slot;
+    ShadowRec* rec;
+    unsigned char* cls;
 };
 
 // Whitted frames of scenes whose shaders do not recurse (Lambert / Phong / Const): what Lambert::shade / Phong::shade need from

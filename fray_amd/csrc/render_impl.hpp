@@ -14,36 +14,30 @@
 namespace frayhip_detail {
 
 namespace {
-// Carves the SoA path-queue arrays out of the workspace.
+// Carves a path queue / a shadow queue of n entries out of the workspace.
 unsigned char* carve_queue(unsigned char* p, size_t n, PathQueue& Q)
 {
     auto take = [&](size_t bytes) { unsigned char* r = p; p += (bytes + 255) / 256 * 256; return r; };
-    Q.ox = (double*)take(n * 8); Q.oy = (double*)take(n * 8); Q.oz = (double*)take(n * 8);
-    Q.dx = (double*)take(n * 8); Q.dy = (double*)take(n * 8); Q.dz = (double*)take(n * 8);
-    Q.tr = (float*)take(n * 4); Q.tg = (float*)take(n * 4); Q.tb = (float*)take(n * 4);
-    Q.slot = (uint32_t*)take(n * 4); Q.depthFlags = (uint32_t*)take(n * 4);
-    Q.rndJ = (uint32_t*)take(n * 4); Q.rndA = (uint32_t*)take(n * 4); Q.rndB = (uint32_t*)take(n * 4);
-    Q.tabJ = (uint32_t*)take(n * 4); Q.tabA = (uint32_t*)take(n * 4); Q.tabB = (uint32_t*)take(n * 4);
+    Q.rec = (PathRec*)take(n * sizeof(PathRec));
+    Q.cls = take(n);
     return p;
 }
 size_t queue_bytes(size_t n)
 {
     auto r = [](size_t b) { return (b + 255) / 256 * 256; };
-    return 6 * r(n * 8) + 11 * r(n * 4);
+    return r(n * sizeof(PathRec)) + r(n);
 }
 unsigned char* carve_shadow(unsigned char* p, size_t n, ShadowQueue& Q)
 {
     auto take = [&](size_t bytes) { unsigned char* r = p; p += (bytes + 255) / 256 * 256; return r; };
-    Q.ax = (double*)take(n * 8); Q.ay = (double*)take(n * 8); Q.az = (double*)take(n * 8);
-    Q.bx = (double*)take(n * 8); Q.by = (double*)take(n * 8); Q.bz = (double*)take(n * 8);
-    Q.cr = (float*)take(n * 4); Q.cg = (float*)take(n * 4); Q.cb = (float*)take(n * 4);
-    Q.slot = (uint32_t*)take(n * 4);
+    Q.rec = (ShadowRec*)take(n * sizeof(ShadowRec));
+    Q.cls = take(n);
     return p;
 }
 size_t shadow_bytes(size_t n)
 {
     auto r = [](size_t b) { return (b + 255) / 256 * 256; };
-    return 6 * r(n * 8) + 4 * r(n * 4);
+    return r(n * sizeof(ShadowRec)) + r(n);
 }
 }  // namespace
 
@@ -246,7 +240,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             // lights.cpp:62-63).  Up to 227 the generators are three registers; beyond that every path gets two 624-word columns (MtPath).
             const bool longRng = 8 + 10 * (set.maxTraceDepth + 2) > 227;
             const size_t termBytes = (size_t)(set.maxTraceDepth + 2) * 12 + 2;       // one FP32 RGB term per bounce and sample, and their count
-            const size_t perPath = 240 + termBytes + (longRng ? 2 * 624 * sizeof(uint32_t) : 0);
+            const size_t perPath = 280 + termBytes + (longRng ? 2 * 624 * sizeof(uint32_t) : 0);
             // Batches of `chunk` samples per pixel; up to FRAY_PT_LANES batches are in flight at once, each on its own
             // stream with its own queues, so one batch's launch gaps, scans and kernel tails are filled by the others'
             // blocks.  Only the resolves are ordered (evResolved): the per-pixel sum runs in sample order.

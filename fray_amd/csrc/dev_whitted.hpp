@@ -35,6 +35,8 @@ struct WhittedLane {
     int shader;
     C3 ret;
     int mode;
+    int spBase;       // activations BELOW this lane's stack that the reference's recursion would hold at this point: 0, except for a glossy fan's child traced ahead
+                      // (k_whitted pass B), which in place runs on top of the fan's own activation and whatever Layered shaders enclose it
 };
 
 struct SpecBuf {
@@ -43,7 +45,7 @@ struct SpecBuf {
     int* eSlot; int* eChildBase;      // per entry: the work item (k * nItems + pixel item), its first child
     double* eo[3];                    //            the children's common origin
     int* cEntry; double* cd[3];       // per child: its entry, its direction
-    float* cc[3]; unsigned char* cok; //            its colour; 1 = traced without a draw
+    float* cc[3]; unsigned char* cok; //            its colour; 1 = traced without a draw (between passes A and B: the stack level the child starts on in place)
     unsigned char* cdraws;            //            how many unit-disc samples its direction took (pass C skips their words instead of redoing the trigonometry), 0 = more than 255
 };
 struct SpecLane { int state, sp, base, looked, missed; };      // 0 = armed, 1 = the fan on stack level sp is being looked up from child `base`, 2 = off until the next sample
@@ -56,7 +58,7 @@ struct MtSpy {
 
 FD void wl_start(WhittedLane& L, V3 o, V3 d)
 {
-    L.sp = 0; L.o = o; L.d = d; L.depth = 0; L.shader = -1; L.ret = c3(0, 0, 0); L.mode = WM_TRACE;
+    L.sp = 0; L.spBase = 0; L.o = o; L.d = d; L.depth = 0; L.shader = -1; L.ret = c3(0, 0, 0); L.mode = WM_TRACE;
 }
 // is the lane at a step that needs no search and no light loop?
 FD bool wl_cheap(const DScene& S, const WhittedLane& L)
@@ -70,7 +72,7 @@ FD void wl_cheap_step(const DScene& S, WhittedLane& L, G& tab, Cnt& c, bool& ove
     if (L.mode == WM_SHADE) {                              // shader->shade(ray, info) of a recursive shader: push its activation
         const FRAY_RO DShader& sh = S.shaders[L.shader];
         const int kind = sh.kind;
-        if (L.sp >= FRAY_WSTACK) { overflow = true; L.sp = 0; L.ret = c3(0, 0, 0); L.mode = WM_ROOT_RET; return; }
+        if (L.sp + L.spBase >= FRAY_WSTACK) { overflow = true; L.sp = 0; L.ret = c3(0, 0, 0); L.mode = WM_ROOT_RET; return; }
         WFrame& f = L.stack[L.sp];
         f.shader = L.shader; f.i = 0; f.count = 0; f.o = L.o; f.d = L.d; f.depth = L.depth; f.info = L.info;
         f.acc = c3(0, 0, 0); f.opacity = c3(0, 0, 0);

@@ -399,6 +399,7 @@ static __global__ __launch_bounds__(256, whitted_waves(ST, MODE)) void k_whitted
                     const int e = SP.cEntry[item];
                     wl_start(L, v3(SP.eo[0][e], SP.eo[1][e], SP.eo[2][e]), v3(SP.cd[0][item], SP.cd[1][item], SP.cd[2][item]));
                     L.depth = 1;
+                    L.spBase = SP.cok[item];                                  // filed by pass A: a child that would overflow the stack in place must overflow here too
                     spy.used = false;
                 } else {
                     const int i = KARG(WhittedArgs, AP, s0) + k;
@@ -463,7 +464,11 @@ static __global__ __launch_bounds__(256, whitted_waves(ST, MODE)) void k_whitted
                     L.mode = WM_NEXT_PIXEL;
                 }
             } else if (L.mode < WM_ROOT_RET && wl_cheap(S, L)) {
-                if (MODE == 2) wl_cheap_step<ST, MtSpy, 0>(S, L, spy, c, ovf, SP, SL);
+                if (MODE == 2) {
+                    bool deep = false;
+                    wl_cheap_step<ST, MtSpy, 0>(S, L, spy, c, deep, SP, SL);
+                    if (deep) spy.used = true;                               // not answered ahead: pass C traces this child in place, where the sample ends as the reference's would
+                }
                 else wl_cheap_step<ST, MtLong, MODE>(S, L, tab, c, ovf, SP, SL);
             }
         }
@@ -507,6 +512,7 @@ static __global__ __launch_bounds__(256, whitted_waves(ST, MODE)) void k_whitted
                         }
                         SP.cEntry[cb + q] = e;
                         SP.cdraws[cb + q] = (unsigned char)(draws <= 255 ? draws : 0);
+                        SP.cok[cb + q] = (unsigned char)L.sp;                 // for pass B: the activations the child finds on the stack in place (the fan's own included)
                         SP.cd[0][cb + q] = reflected.x; SP.cd[1][cb + q] = reflected.y; SP.cd[2][cb + q] = reflected.z;
                     }
                     L.sp = 0;
@@ -883,7 +889,13 @@ FD uint32_t seg_map(const FRAY_RO uint32_t* off, const FRAY_RO uint32_t* nf, uin
 // Which kernel variants sort: the ones that walk KD-trees (boxed.fray path traced at 960 x 540 x 16 spp: 65.3 -> 54.9 ms).  Without a tree the order costs more than it saves:
 // cornell_box's bounce kernel issues 11 % fewer instructions sorted and takes 3 % less time, its shadow kernel 11 % MORE time (two passes of LDS atomics and segment look-ups
 // per entry, against ~600 instructions a shadow ray costs there), smallpt -- planes and spheres, nothing to leave early -- +31 % / +70 %; the Cube / CSG variants +3 %.
+#ifdef FRAY_SORT_BY_MATERIAL
+// Experiment (profiles/r05_experiments/README.md, "binning by material"): EVERY variant sorts, and a path's class is the shader kind that spawned its ray
+// (Lambert / mirror / glass / other) instead of its direction -- north_star's sort-by-material, as far as a queue between bounces can know a material.
+constexpr bool sort_variant(int) { return true; }
+#else
 constexpr bool sort_variant(int st) { return (st & 6) == 4; }
+#endif
 FD void wave_lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1118,6 +1130,9 @@ FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitT<ST>& h, const 
         {
             ps.pm = ps.pm * brdf / pdf;
             ps.o = wout.o; ps.d = wout.d; ps.depth = wout.depth; ps.flags = wout.flags;
+#ifdef FRAY_SORT_BY_MATERIAL
+            ps.flags = (ps.flags & 0xffu) | ((sh.kind == 1 ? 0u : sh.kind == 3 ? 1u : sh.kind == 4 ? 2u : 3u) << 8);      // experiment: the spawning shader's kind rides in the flags
+#endif
             // entry test of the next pathtrace() call (main.cpp:173-176): it returns black, this bounce's term stays the light contribution
             if (ps.depth > S.maxTraceDepth || intensity(ps.pm) < 0.01) path_finish(TB, st, ps, SB);
             else cont = true;
@@ -1252,7 +1267,11 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
         // the front, the others to the back (ballot ranks, no global counter)
         const bool back = cont && ray_gate_class(S, ps.o, ps.d);
         const uint32_t slotOut = seg_slot(outEnds, cont, back);
+#ifdef FRAY_SORT_BY_MATERIAL
+        if (cont) path_store(Qout, slotOut, ps, (ps.flags >> 8) & 3u);
+#else
         if (cont) path_store(Qout, slotOut, ps, ray_sort_class(ps.d, back));
+#endif
         seg_advance(outEnds, cont, back);
         STAMP(13);
     }

@@ -154,9 +154,20 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                         if (fan > 0) {
                             WhittedArgs WB = WA, WC = WA;
                             WB.cur = cursors + 1; WC.cur = cursors + 2;
+                            // three launches, three event pairs: frayhip_stats.trace_launches counts LAUNCHES (round 4 timed the three as one and reported
+                            // launches_per_step 1, which no per-kernel profile could agree with)
+                            hipEvent_t b1 = pool_event(sc->evPool, nTraceEvents + 2), b2 = pool_event(sc->evPool, nTraceEvents + 3);
+                            hipEvent_t c1 = pool_event(sc->evPool, nTraceEvents + 4), c2 = pool_event(sc->evPool, nTraceEvents + 5);
+                            if (!b1 || !b2 || !c1 || !c2) return FRAYHIP_E_NOMEM;
                             hipLaunchKernelGGL((k_whitted<ST, 1>), dim3(gridAC), dim3(256), 0, stream, WA);   // samples; fans are filed
+                            HIP_TRY(hipEventRecord(b, stream));
+                            HIP_TRY(hipEventRecord(b1, stream));
                             hipLaunchKernelGGL((k_whitted<ST, 2>), dim3(persistent_grid((size_t)nItems * cn * (size_t)fan, whitted_waves(ST, 2))), dim3(256), 0, stream, WB);     // the fans' children
+                            HIP_TRY(hipEventRecord(b2, stream));
+                            HIP_TRY(hipEventRecord(c1, stream));
                             hipLaunchKernelGGL((k_whitted<ST, 3>), dim3(gridAC), dim3(256), 0, stream, WC);   // the filed samples, children looked up
+                            nTraceEvents += 4;
+                            b = c2;
                         } else {
                             hipLaunchKernelGGL((k_whitted<ST, 0>), dim3(grid), dim3(256), 0, stream, WA);
                         }

@@ -439,7 +439,7 @@ def main():
         from tools.source_hash import source_hash
         src = source_hash()
         # the kernel whose launches ms_trace / alg_flops_trace describe, and the one behind ms_shadow / alg_flops_shadow
-        wavefront_whitted = mode == abi.MODE_RENDER and not scene.settings.gi and shadow_launches > 0
+        wavefront_whitted = mode == abi.MODE_RENDER and not scene.settings.gi and scene.get_option("whitted_path") in (1, 2)
         kern = {abi.MODE_PRIMARY_ID: "k_primary"}.get(mode, "k_pt_bounce" if scene.settings.gi else ("k_wh_shade" if wavefront_whitted else "k_whitted"))
         kern_shadow = "k_pt_shadow" if scene.settings.gi else "k_wh_visible"
         # launch durations: serialised pass for path tracing, the timed region itself otherwise (one kernel, one stream)
@@ -467,6 +467,8 @@ def main():
             "config": {"workload": desc_text, "width": W, "height": H, "spp": scene.samples_per_pixel(),
                        "rays_per_frame": rays_total, "camera_samples_per_frame": float(counts[2]),
                        "arith": args.arith,
+                       **({"whitted_path": {0: "k_whitted (recursive shaders)", 1: "k_wh_shade -> k_wh_visible -> k_wh_gather", 2: "k_wh_shade, fused (visible() in place)"}[scene.get_option("whitted_path")]}
+                          if mode == abi.MODE_RENDER and not scene.settings.gi else {}),
                        "parallelism": "tiles%d" % world if world > 1 else ("rank %d's share of tiles%d, no exchange (diagnosis)" % (args.shard_rank, args.shard_of) if args.shard_of > 1 else "single-gpu"),
                        "frame_ms": ms_per_step, "msamples_per_s": float(counts[2]) / (ms_per_step * 1e-3) / 1e6,
                        # glossy fans drawn and traced ahead in the last timed frame (frayhip_scene_get_option; zero unless the scene has such fans and no sampling light)

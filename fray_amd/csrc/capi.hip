@@ -552,6 +552,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         put3(o.center, l.center);
         o.area = l.area;
         sc->lightSampleCount += l.kind == FRAYHIP_LIGHT_RECT ? l.xSubd * l.ySubd : 1;
+        if (l.kind == FRAYHIP_LIGHT_RECT) sc->lightDraws = true;
         if (l.kind == FRAYHIP_LIGHT_RECT) anyLightDraws = true;          // RectLight::getNthSample draws two words per sample (lights.cpp:62-63)
         o.areaXsize = 1.0 / l.xSubd;
         o.areaYsize = 1.0 / l.ySubd;
@@ -598,6 +599,52 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
             for (int k = 0; k < 3; k++) { X.bminE[k] = N.bmin[k] - 1e-6; X.bmaxE[k] = N.bmax[k] + 1e-6; }
         }
     }
+    // Bounds of a geometry tree in its own (local) space: every point an intersection of the tree can lie on.  Plus: both operands; Minus: the left one
+    // (a ray that has no intersection with the left operand is never inside the difference); And: either operand alone bounds the result, the smaller
+    // box is taken.  A Plane operand makes its tree unbounded (ok = false) unless the operator hides it.
+    struct GB { bool ok; double lo[3], hi[3]; };
+    std::function<GB(int, int)> bounds = [&](int g, int depth) -> GB {
+        GB b{true, {0, 0, 0}, {0, 0, 0}};
+        if (g < 0 || g >= d.n_geoms || depth > FRAY_CSG_DEPTH + 1) { b.ok = false; return b; }
+        const int kind = d.geoms[g].kind, idx = d.geoms[g].index;
+        if (kind == FRAYHIP_GEOM_PLANE) {
+            // never bounded here: Plane::intersect divides 0 by 0 for a horizontal ray that starts at the plane's height and then reports a hit at NaN
+            // (geometry.cpp:35-41: no comparison with NaN is true), wherever the ray is -- no box holds that
+            b.ok = false; return b;
+        } else if (kind == FRAYHIP_GEOM_SPHERE) {
+            for (int k = 0; k < 3; k++) { b.lo[k] = d.spheres[idx].O[k] - std::fabs(d.spheres[idx].R); b.hi[k] = d.spheres[idx].O[k] + std::fabs(d.spheres[idx].R); }
+        } else if (kind == FRAYHIP_GEOM_CUBE) {
+            for (int k = 0; k < 3; k++) { b.lo[k] = d.cubes[idx].O[k] - std::fabs(d.cubes[idx].halfSide); b.hi[k] = d.cubes[idx].O[k] + std::fabs(d.cubes[idx].halfSide); }
+        } else if (kind == FRAYHIP_GEOM_MESH) {
+            for (int k = 0; k < 3; k++) { b.lo[k] = d.meshes[idx].bbox_min[k]; b.hi[k] = d.meshes[idx].bbox_max[k]; }
+        } else if (kind == FRAYHIP_GEOM_CSG) {
+            const frayhip_csg& C = d.csgs[idx];
+            const GB L = bounds(C.left, depth + 1), R = bounds(C.right, depth + 1);
+            auto vol = [](const GB& q) { return (q.hi[0] - q.lo[0]) * (q.hi[1] - q.lo[1]) * (q.hi[2] - q.lo[2]); };
+            if (C.op == FRAYHIP_CSG_MINUS) return L;
+            if (C.op == FRAYHIP_CSG_AND) { if (L.ok && R.ok) return vol(L) <= vol(R) ? L : R; return L.ok ? L : R; }
+            if (!L.ok || !R.ok) { b.ok = false; return b; }
+            for (int k = 0; k < 3; k++) { b.lo[k] = std::min(L.lo[k], R.lo[k]); b.hi[k] = std::max(L.hi[k], R.hi[k]); }
+        } else b.ok = false;
+        for (int k = 0; k < 3; k++) if (!(std::isfinite(b.lo[k]) && std::isfinite(b.hi[k]) && b.lo[k] <= b.hi[k])) b.ok = false;
+        return b;
+    };
+    std::vector<GB> csgLocal(d.n_nodes, GB{false, {0, 0, 0}, {0, 0, 0}});
+    for (int i = 0; i < d.n_nodes; i++) {
+        DNodeX& X = nodesX[i];
+        for (int k = 0; k < 3; k++) X.cc[k] = X.ch[k] = 0;
+        X.cM = 0; X.csgBox = 0; X.padX = 0;
+        if (nodes[i].geomKind != FRAYHIP_GEOM_CSG) continue;
+        const GB b = bounds(d.nodes[i].geom, 0);
+        if (!b.ok) continue;
+        csgLocal[i] = b;
+        for (int k = 0; k < 3; k++) {
+            X.cc[k] = 0.5 * (b.lo[k] + b.hi[k]);
+            X.ch[k] = std::max(b.hi[k] - X.cc[k], X.cc[k] - b.lo[k]) * (1.0 + 1e-12) + 1e-5;       // the true extents and dev_misscert.hpp's constant margin
+            X.cM = std::max(X.cM, std::fabs(X.cc[k]) + X.ch[k]);
+        }
+        X.csgBox = X.cM < 1e9 ? 1 : 0;
+    }
     if (!nodes.empty()) memcpy(A.host.data() + oNodes, nodes.data(), nodes.size() * sizeof(DNode));
     if (!nodesX.empty()) memcpy(A.host.data() + oNodesX, nodesX.data(), nodesX.size() * sizeof(DNodeX));
     // gates: world-space boxes of the meshes whose brute-force triangle loops are worth skipping for a whole wave (dev_scene.hpp DGate):
@@ -605,13 +652,24 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     int nGates = 0;
     {
         DGate gates[FRAY_MAX_GATES];
+        // ... and of the CsgOp nodes whose tree is bounded (their machine is the most expensive thing a ray can enter), unless the box is so large
+        // against the others that nearly every ray enters it anyway (a floor slab): larger than 30 times the smallest such box in some extent
+        double smallest = 1e300;
+        for (int i = 0; i < d.n_nodes; i++)
+            if (csgLocal[i].ok) for (int k = 0; k < 3; k++) smallest = std::min(smallest, std::max(csgLocal[i].hi[k] - csgLocal[i].lo[k], 1e-9));
         for (int i = 0; i < d.n_nodes && nGates < FRAY_MAX_GATES; i++) {
             const DNode& N = nodes[i];
-            if (N.tlTris < FRAY_GATE_MIN_TRIS) continue;
+            double bmin[3], bmax[3];
+            if (N.tlTris >= FRAY_GATE_MIN_TRIS) { put3(bmin, N.bmin); put3(bmax, N.bmax); }
+            else if (csgLocal[i].ok) {
+                bool huge = false;
+                for (int k = 0; k < 3; k++) { bmin[k] = csgLocal[i].lo[k]; bmax[k] = csgLocal[i].hi[k]; huge = huge || bmax[k] - bmin[k] > 30.0 * smallest; }
+                if (huge) continue;
+            } else continue;
             DGate g;
             for (int k = 0; k < 3; k++) { g.lo[k] = 1e300; g.hi[k] = -1e300; }
             for (int c = 0; c < 8; c++) {
-                const double p[3] = {c & 1 ? N.bmax[0] : N.bmin[0], c & 2 ? N.bmax[1] : N.bmin[1], c & 4 ? N.bmax[2] : N.bmin[2]};
+                const double p[3] = {c & 1 ? bmax[0] : bmin[0], c & 2 ? bmax[1] : bmin[1], c & 4 ? bmax[2] : bmin[2]};
                 for (int k = 0; k < 3; k++) {
                     const double w = p[0] * N.T.m[k] + p[1] * N.T.m[3 + k] + p[2] * N.T.m[6 + k] + N.T.off[k];
                     g.lo[k] = std::min(g.lo[k], w); g.hi[k] = std::max(g.hi[k], w);
@@ -666,6 +724,8 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     if (const char* e = getenv("FRAYHIP_PT_LANES")) { long v = atol(e); if (v >= 1 && v <= FRAY_PT_LANES) sc->ptLanes = (int)v; }
     if (const char* e = getenv("FRAYHIP_SPECULATE_FANS")) sc->speculateFans = atol(e) != 0;
     if (const char* e = getenv("FRAYHIP_FP_CONTRACT")) sc->fpContract = atol(e) == 1;
+    if (const char* e = getenv("FRAYHIP_FUSED_WHITTED_MAX")) { long v = atol(e); if (v >= 0 && v <= 1024) sc->fusedWhittedMax = (int)v; }
+    if (const char* e = getenv("FRAYHIP_CSG_LANES")) { long v = atol(e); if (v >= 1 && v <= FRAY_PT_LANES) sc->csgLanes = (int)v; }
     if (const char* e = getenv("FRAYHIP_PT_BUDGET_MIB")) { long v = atol(e); if (v >= 1 && v <= (1 << 20)) { sc->ptBudgetBytes = (size_t)v << 20; sc->ptBudgetEff = 0; } }
     *out = sc;
     return FRAYHIP_OK;
@@ -680,6 +740,8 @@ int frayhip_scene_get_option(frayhip_scene* s, const char* name, int64_t* value)
     else if (n == "speculate_fans") *value = s->speculateFans ? 1 : 0;
     else if (n == "fp_contract") *value = s->fpContract ? 1 : 0;
     else if (n == "contracted_launches") *value = s->lastContracted;
+    else if (n == "whitted_path") *value = s->lastWhittedPath;
+    else if (n == "fused_whitted_max") *value = s->fusedWhittedMax;
     else if (n == "pt_budget_effective_mib") *value = (int64_t)(frayhip_detail::work_budget(s) >> 20);
     else if (n == "fans_filed") *value = s->lastFans[0];
     else if (n == "fan_children") *value = s->lastFans[1];
@@ -703,6 +765,9 @@ int frayhip_scene_set_option(frayhip_scene* s, const char* name, int64_t value)
     } else if (n == "speculate_fans") {
         if (value != 0 && value != 1) { set_error("frayhip_scene_set_option: speculate_fans must be 0 or 1"); return FRAYHIP_E_ARG; }
         s->speculateFans = value != 0;
+    } else if (n == "fused_whitted_max") {
+        if (value < 0 || value > 1024) { set_error("frayhip_scene_set_option: fused_whitted_max must be 0..1024"); return FRAYHIP_E_ARG; }
+        s->fusedWhittedMax = (int)value;
     } else if (n == "fp_contract") {
         if (value != 0 && value != 1) { set_error("frayhip_scene_set_option: fp_contract must be 0 or 1"); return FRAYHIP_E_ARG; }
         s->fpContract = value != 0;

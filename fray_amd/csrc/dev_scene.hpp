@@ -58,6 +58,11 @@ struct DNode {
 // What only the box test of the scenes WITHOUT KD meshes reads (DScene::nodesX): the node's box widened by inside()'s tolerance
 struct DNodeX {
     double bminE[3], bmaxE[3];   // bmin - 1e-6, bmax + 1e-6: what BBox::inside compares with (bbox.h:81-83), computed once on the host
+    // A CsgOp node whose tree is bounded (no unbounded operand where it matters): centre and half extents of a LOCAL-space box that holds every
+    // geometry an intersection of the tree can come from, widened by 1e-5, and M = max_k (|c_k| + h_k) -- what ray_surely_misses_box
+    // (dev_misscert.hpp) needs to let a ray that passes the object by skip CsgOp::intersect altogether.  csgBox = 0: no such box.
+    double cc[3], ch[3], cM;
+    int32_t csgBox, padX;
 };
 
 struct DPlane { double limit, height; };

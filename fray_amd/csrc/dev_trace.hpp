@@ -19,6 +19,7 @@
 #include "dev_sort.hpp"
 #define FRAY_CERT_SEQ() __builtin_amdgcn_sched_barrier(0)
 #include "dev_boxcert.hpp"
+#include "dev_misscert.hpp"
 
 #ifdef FRAY_LEAFSTAT
 static __device__ unsigned long long g_leafStat[4];      // diagnostic build only, read back by render_impl (FRAY_LEAFSTAT)
@@ -556,26 +557,32 @@ struct CsgFrame {
 template <int ST>
 FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win, bool& envelope, Cnt& c)
 {
+    // The activation on top of the stack lives in registers (F); fr[] holds the ones below it and is touched only when a CsgOp operand is entered or
+    // left.  (Round 4 indexed fr[level] for every field: a scratch access each, on the path every ray of a scene with a CSG floor takes.)
     CsgFrame fr[FRAY_CSG_DEPTH];
     double dist[FRAY_CSG_DEPTH][2 * FRAY_CSG_MAX];
     unsigned char order[FRAY_CSG_DEPTH][2 * FRAY_CSG_MAX];
     int level = 0, quietAt = -1;
     V3 start = s;
-    fr[0].s[0] = s.x; fr[0].s[1] = s.y; fr[0].s[2] = s.z;
-    fr[0].csg = rootCsg; fr[0].n = fr[0].k = fr[0].cnt0 = fr[0].cnt1 = fr[0].winOp = fr[0].winK = fr[0].pass = fr[0].op = 0;
+    CsgFrame F;
+    F.s[0] = s.x; F.s[1] = s.y; F.s[2] = s.z;
+    F.winDist = 0;
+    F.csg = rootCsg; F.n = F.k = F.cnt0 = F.cnt1 = F.winOp = F.winK = F.pass = F.op = 0;
     for (;;) {
         // ---- ASK
         bool ok;
         GHit h;
         {
-            const FRAY_RO DCsg& G = S.csgs[fr[level].csg];
-            const int op = fr[level].op;
+            const FRAY_RO DCsg& G = S.csgs[F.csg];
+            const int op = F.op;
             const int kind = op == 0 ? G.leftKind : G.rightKind, index = op == 0 ? G.leftIndex : G.rightIndex;
             if (kind == 4) {
                 if (level + 1 < FRAY_CSG_DEPTH) {
+                    fr[level] = F;
                     level++;
-                    fr[level].s[0] = start.x; fr[level].s[1] = start.y; fr[level].s[2] = start.z;
-                    fr[level].csg = index; fr[level].n = fr[level].k = fr[level].cnt0 = fr[level].cnt1 = fr[level].winOp = fr[level].winK = fr[level].pass = fr[level].op = 0;
+                    F.s[0] = start.x; F.s[1] = start.y; F.s[2] = start.z;
+                    F.winDist = 0;
+                    F.csg = index; F.n = F.k = F.cnt0 = F.cnt1 = F.winOp = F.winK = F.pass = F.op = 0;
                     continue;
                 }
                 envelope = true;          // unreachable: frayhip_scene_create rejects deeper trees
@@ -593,7 +600,6 @@ FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win
         }
         // ---- DELIVER, until an activation asks again
         for (;;) {
-            CsgFrame& F = fr[level];
             const V3 fs = v3(F.s[0], F.s[1], F.s[2]);
             bool answer = false;                                  // this activation is done: (ok, h) is ITS answer
             if (ok && F.pass == 0 && F.k == FRAY_CSG_MAX) ok = false;          // `counter-- > 0`: the 31st intersection is found and dropped
@@ -638,6 +644,7 @@ FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win
             if (quietAt == level) quietAt = -1;
             if (level == 0) { win = h; return ok; }
             level--;
+            F = fr[level];
         }
     }
 }
@@ -695,6 +702,13 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, L
         return true;
     }
     if ((ST & 2) && N.geomKind == 4) {   // CSG: the winner is re-derived in finalize_hit
+        if constexpr (!(ST & 1)) {
+            // The reference's CsgOp has no bounding volume: every ray of the scene runs findAllIntersections on both operand trees.  A ray that
+            // CERTIFIABLY passes the tree's bounding box by (dev_misscert.hpp: then no operand reports an intersection, as the reference computes
+            // them) gets the reference's answer -- none -- without the machine.  (The counting variants run it: their counters are the reference's calls.)
+            const FRAY_RO DNodeX& X = S.nodesX[nodeIndex];
+            if (X.csgBox && ray_surely_misses_box(X.cc[0], X.cc[1], X.cc[2], X.ch[0], X.ch[1], X.ch[2], X.cM, ls.x, ls.y, ls.z, ld.x, ld.y, ld.z)) return false;
+        }
         GHit h;
         bool env = false;
         if (!csg_intersect<ST>(S, N.geomIndex, ls, ld, ray_rdir(ld), h, env, c)) return false;

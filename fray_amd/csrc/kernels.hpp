@@ -553,8 +553,11 @@ static __global__ __launch_bounds__(256, whitted_waves(ST, MODE)) void k_whitted
 //   k_wh_gather   per camera sample: result = base + sum over lights of (sum of the visible samples' terms) / ns, the reference's
 //                 FP32 order; then k_pt_resolve sums the samples of a pixel in order
 // visible() draws no random numbers, so evaluating it after the light loops changes nothing.
-template <int ST>
-FD void wh_shade_eye(const DScene& S, V3 o, V3 d, MtLong& tab, const WhittedQueue& Q, size_t N, size_t e, Cnt& c)
+// FUSED: visible() is asked in place and the sample's colour returned (`fused`), in Lambert / Phong::shade's own order of additions (shading.cpp:54-78) -- for
+// scenes whose lights take a handful of samples per hit (zaphod, forest: ONE point light), where the three launches of the wavefront cost more than the
+// shadow rays they lay side by side.  Nothing is queued then.
+template <int ST, bool FUSED = false>
+FD void wh_shade_eye(const DScene& S, V3 o, V3 d, MtLong& tab, const WhittedQueue& Q, size_t N, size_t e, Cnt& c, C3* fused = nullptr)
 {
     HitT<ST> h;
     closest_hit<ST>(S, o, d, h, c);
@@ -577,12 +580,13 @@ FD void wh_shade_eye(const DScene& S, V3 o, V3 d, MtLong& tab, const WhittedQueu
             hit = 1;
             const V3 n = faceforward(d, info.norm);
             const V3 a = info.ip + n * 1e-6;
-            Q.ax[e] = a.x; Q.ay[e] = a.y; Q.az[e] = a.z;
+            if constexpr (!FUSED) { Q.ax[e] = a.x; Q.ay[e] = a.y; Q.az[e] = a.z; }
             size_t t = e;
             const int nl = S.nLights;
             for (int li = 0; li < nl; li++) {
                 const FRAY_RO DLight& L = S.lights[li];
                 const int ns = light_num_samples(L);
+                C3 sum = c3(0, 0, 0);
                 for (int k = 0; k < ns; k++, t += N) {
                     C3 lc;
                     V3 lp;
@@ -600,18 +604,26 @@ FD void wh_shade_eye(const DScene& S, V3 o, V3 d, MtLong& tab, const WhittedQueu
                         if (cosCam > 0)
                             r = r + lc / (float)lightDistSqr * ldc(sh.specularColor) * (float)pow(cosCam, sh.exponent) * (float)sh.specularMultiplier;
                     }
-                    Q.bx[t] = lp.x; Q.by[t] = lp.y; Q.bz[t] = lp.z;
-                    Q.rr[t] = r.r; Q.rg[t] = r.g; Q.rb[t] = r.b;
+                    if constexpr (FUSED) {
+                        if (visible<ST>(S, a, lp, c)) sum = sum + r;
+                    } else {
+                        Q.bx[t] = lp.x; Q.by[t] = lp.y; Q.bz[t] = lp.z;
+                        Q.rr[t] = r.r; Q.rg[t] = r.g; Q.rb[t] = r.b;
+                    }
                 }
+                if constexpr (FUSED) base = base + sum / (float)ns;             // result += sum / numSamples, light after light (k_wh_gather's order)
             }
         }
     }
+    if constexpr (FUSED) { *fused = base; return; }
     Q.base[3 * e] = base.r; Q.base[3 * e + 1] = base.g; Q.base[3 * e + 2] = base.b;
     Q.hit[e] = hit;
 }
 
-struct WhShadeArgs { DScene S; DCamera C; DFrame F; int nItems, s0, chunk; WhittedQueue Q; uint32_t* mtWork; const uint32_t* x397; DStats* st; DCursors* cur; };
-template <int ST>
+// radL / radR / rgb: the fused form's outputs -- the samples' colours for k_pt_resolve, or, for a mono frame of one sample per pixel, the pixel itself (rgb != nullptr).
+// x397 == nullptr (fused form only): no generator of this frame can be asked for a word (no jitter, no lens, no sampling light), none is seeded.
+struct WhShadeArgs { DScene S; DCamera C; DFrame F; int nItems, s0, chunk; WhittedQueue Q; uint32_t* mtWork; const uint32_t* x397; DStats* st; DCursors* cur; float* radL; float* radR; float* rgb; };
+template <int ST, bool FUSED = false>
 static __global__ __launch_bounds__(256, waves_for(ST, FRAY_WH_SHADE_WAVES)) void k_wh_shade(WhShadeArgs A)
 {
     Cnt c = zero_cnt();
@@ -643,16 +655,18 @@ static __global__ __launch_bounds__(256, waves_for(ST, FRAY_WH_SHADE_WAVES)) voi
         const int item = (int)(slot % (uint32_t)nItems), s = (int)(slot / (uint32_t)nItems);
         int x, y;
         if (!item_pixel(F, item, x, y)) {                 // ragged edge bucket: nothing to shade, nothing to test
-            for (int eye = 0; eye < (stereo ? 2 : 1); eye++) {
-                const size_t e = (size_t)eye * total + slot;
-                Q.hit[e] = 0;
-                Q.base[3 * e] = 0; Q.base[3 * e + 1] = 0; Q.base[3 * e + 2] = 0;
+            if constexpr (!FUSED) {
+                for (int eye = 0; eye < (stereo ? 2 : 1); eye++) {
+                    const size_t e = (size_t)eye * total + slot;
+                    Q.hit[e] = 0;
+                    Q.base[3 * e] = 0; Q.base[3 * e + 1] = 0; Q.base[3 * e + 2] = 0;
+                }
             }
             continue;
         }
         const int i = s0 + s;
         const uint32_t p = (uint32_t)y * (uint32_t)F.W + (uint32_t)x;
-        tab.reseed_with(sample_seed(F.seed, p, (uint32_t)i), x397[slot]);
+        if (!FUSED || x397) tab.reseed_with(sample_seed(F.seed, p, (uint32_t)i), x397[slot]);
         Mt rnd = tab.r;
         float ox, oy;
         if (F.jitter) { ox = rng_float(rnd); oy = rng_float(rnd); }
@@ -671,14 +685,28 @@ static __global__ __launch_bounds__(256, waves_for(ST, FRAY_WH_SHADE_WAVES)) voi
             if (C.dof) dof_ray(C, fx, fy, tab, o, d); else screen_ray(C, fx, fy, o, d);
             bump<ST>(c.samples);
         }
-        ovf = ovf || rnd.j > 227;
+        if (!FUSED || x397) ovf = ovf || rnd.j > 227;              // (an unseeded generator -- nothing of this frame draws -- holds no count)
         for (int eye = 0; eye < (stereo ? 2 : 1); eye++) {          // one copy of the trace-and-shade code for both eyes
             if (eye == 1) {
                 o = v3(rightRay[0][threadIdx.x], rightRay[1][threadIdx.x], rightRay[2][threadIdx.x]);
                 d = v3(rightRay[3][threadIdx.x], rightRay[4][threadIdx.x], rightRay[5][threadIdx.x]);
             }
             STAMP(0);
-            wh_shade_eye<ST>(S, o, d, tab, Q, N, (size_t)eye * total + slot, c);
+            if constexpr (FUSED) {
+                C3 col;
+                wh_shade_eye<ST, true>(S, o, d, tab, Q, N, (size_t)eye * total + slot, c, &col);
+                float* const rgb = KARG(WhShadeArgs, AP, rgb);
+                if (rgb) {                                            // vfb[y][x] = (0 + sample) / 1, main.cpp:348-360
+                    const C3 avg = (c3(0, 0, 0) + col) / 1.0f;
+                    const size_t q = ((size_t)y * F.W + x) * 3;
+                    rgb[q] = avg.r; rgb[q + 1] = avg.g; rgb[q + 2] = avg.b;
+                } else {
+                    float* const out = (eye == 0 ? KARG(WhShadeArgs, AP, radL) : KARG(WhShadeArgs, AP, radR)) + 3 * (size_t)slot;
+                    out[0] = col.r; out[1] = col.g; out[2] = col.b;
+                }
+            } else {
+                wh_shade_eye<ST>(S, o, d, tab, Q, N, (size_t)eye * total + slot, c);
+            }
             STAMP(10);
         }
     }

@@ -93,6 +93,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             if (nItems > 0) hipLaunchKernelGGL(k_black, dim3(grid_for(nItems)), dim3(256), 0, stream, F, nItems, sc->camera.stereoSeparation > 0 ? 2 : 1, d_rgb, sc->d_stats);
         } else if (!set.gi) {
             if (!F.jitter && spp > 5) { set_error("frayhip_render: bad sample count"); return FRAYHIP_E_ARG; }
+            sc->lastWhittedPath = 0;
             if (nItems > 0 && sc->whittedNeedsRecursion) {
                 // workspace: per-thread mt19937 state columns for samples that draw more than 227 words, the pixels' running sums, then per
                 // (pixel, sample) of a batch the sample's colour and x[397] of its seed.  A work item of k_whitted is one camera sample, so the
@@ -221,10 +222,17 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 float* radL = (float*)take(slots * 12);
                 float* radR = (float*)take(slots * 12);
                 uint32_t* x397 = (uint32_t*)take(slots * 4);
+                // Few light samples per hit (zaphod, forest: one point light): the fused form of k_wh_shade asks visible() in place -- one launch instead of
+                // shade + visible + gather; no k_seed when no generator can be asked for a word; no resolve when the kernel writes the pixel itself.
+                // (not beside KD meshes: there the fused kernel spills 165 registers and the lean any-hit kernel wins -- forest DOF 256 162.4 against 168.2 ms fused)
+                const bool fusedShade = T <= sc->fusedWhittedMax && !kd_variant(ST);
+                sc->lastWhittedPath = fusedShade ? 2 : 1;
+                const bool draws = F.jitter || sc->camera.dof || sc->lightDraws;
                 for (int s0 = 0; s0 < spp; s0 += chunk) {
                     const int cn = std::min(chunk, spp - s0);
                     const size_t bs = (size_t)nItems * cn, bN = bs * eyes;      // this batch's slots: arrays are used with stride bN
-                    hipLaunchKernelGGL(k_seed, dim3(seed_grid((bs + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
+                    if (!fusedShade || draws)
+                        hipLaunchKernelGGL(k_seed, dim3(seed_grid((bs + FRAY_SEED_CHAINS - 1) / FRAY_SEED_CHAINS)), dim3(256), 0, stream, F, nItems, s0, cn, x397);
                     hipEvent_t ea = pool_event(sc->evPool, nTraceEvents), eb = pool_event(sc->evPool, nTraceEvents + 1);
                     hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
                     if (!ea || !eb || !ec || !ed) return FRAYHIP_E_NOMEM;
@@ -232,9 +240,18 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     if (s0 > 0) HIP_TRY(hipMemsetAsync(cursors, 0, 2 * sizeof(DCursors), stream));        // the previous batch's tile cursors (one set per kernel)
                     // tiles are claimed when a wave gets at least 16 of them, walked with a fixed stride otherwise (next_tile, kernels.hpp)
                     const bool claimShade = bs / 64 >= (size_t)grid * 4 * 16;
+                    if (fusedShade) {
+                        const bool direct = spp == 1 && !stereo;
+                        hipLaunchKernelGGL((k_wh_shade<ST, true>), dim3(grid), dim3(256), 0, stream,
+                                           WhShadeArgs{S, C, F, nItems, s0, cn, Q, mtWork, draws ? x397 : nullptr, sc->d_stats, claimShade ? cursors : nullptr, radL, radR, direct ? d_rgb : nullptr});
+                        HIP_TRY(hipEventRecord(eb, stream));
+                        nTraceEvents += 2;
+                        if (!direct) hipLaunchKernelGGL(k_pt_resolve, dim3(grid_for(nItems)), dim3(256), 0, stream, F, C, set.saturation, nItems, s0, cn, radL, stereo ? radR : nullptr, sum, d_rgb);
+                        continue;
+                    }
                     const int gridVis = persistent_grid(bN * (size_t)T, anyhit_waves(ST));
                     const bool claimVis = (bN * (size_t)T) / 64 >= (size_t)gridVis * 4 * 16;
-                    hipLaunchKernelGGL(k_wh_shade<ST>, dim3(grid), dim3(256), 0, stream, WhShadeArgs{S, C, F, nItems, s0, cn, Q, mtWork, x397, sc->d_stats, claimShade ? cursors : nullptr});
+                    hipLaunchKernelGGL(k_wh_shade<ST>, dim3(grid), dim3(256), 0, stream, WhShadeArgs{S, C, F, nItems, s0, cn, Q, mtWork, x397, sc->d_stats, claimShade ? cursors : nullptr, nullptr, nullptr, nullptr});
                     HIP_TRY(hipEventRecord(eb, stream));
                     nTraceEvents += 2;
                     HIP_TRY(hipEventRecord(ec, stream));
@@ -259,7 +276,29 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             // The Cube / CSG kernel variants keep their hit lists in scratch memory (17 KB per lane at sixteen CsgOp levels): every stream that runs
             // one needs its own scratch arena, and three streams asking for theirs at once aborted inside the runtime (tests/test_fuzz_parity.py,
             // seed 5).  Those scenes run their batches one after the other.
-            if (ST & 2) maxLanes = 1;
+            if (ST & 2) {
+                maxLanes = std::max(1, std::min(maxLanes, sc->csgLanes));
+                // Round 5: the streams get their scratch arenas ONE AFTER THE OTHER before any batch runs -- an empty launch of each of the two kernels on
+                // every lane's stream, each waited for -- so that no two streams ask the runtime for an arena at the same moment.
+                if (maxLanes > 1 && !sc->csgWarm) {
+                    HIP_TRY(hipMemsetAsync(sc->d_qmeta, 0, 3 * FRAY_PT_LANES * sizeof(QMeta), stream));
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    for (int k = 0; k < maxLanes; k++) {
+                        hipStream_t ws = k == 0 ? stream : sc->laneStream[k];
+                        QMeta* m = sc->d_qmeta + 3 * k;
+                        const QMetaRO mIn{(const FRAY_RO QMeta*)m};
+                        BounceArgs BA{};
+                        BA.S = S; BA.metaIn = mIn; BA.metaOut = m + 1; BA.metaShadow = m + 2; BA.st = sc->d_stats;
+                        hipLaunchKernelGGL((k_pt_bounce<ST, false>), dim3(1), dim3(256), 0, ws, BA);
+                        hipLaunchKernelGGL((k_pt_bounce<ST, false, true>), dim3(1), dim3(256), 0, ws, BA);
+                        ShadowArgs SA{};
+                        SA.S = S; SA.meta = mIn; SA.st = sc->d_stats + 1;
+                        hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(1), dim3(256), 0, ws, SA);
+                        HIP_TRY(hipStreamSynchronize(ws));
+                    }
+                    sc->csgWarm = true;
+                }
+            }
             // a small frame (an eighth of 1080p x 64 spp, i.e. one rank's share of an 8-rank run) is cut into fewer, larger batches:
             // measured 15.5 ms on three lanes against 15.9 on four; from a quarter of that frame upwards four lanes win
             if (maxLanes > 3 && (size_t)nItems * (size_t)spp < ((size_t)24 << 20)) maxLanes = 3;
@@ -276,7 +315,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                 nLanes = std::min(nBatches, maxLanes);
                 nPaths = (size_t)nItems * chunk;
                 // per-wave segments round their share up to a multiple of 64: one extra wave-load per wave of the grid
-                nQueue = nPaths + (size_t)bounce_grid(nPaths, (ST & 2) != 0) * 4 * 128;
+                nQueue = nPaths + (size_t)bounce_grid(nPaths, (ST & 2) != 0 && maxLanes == 1) * 4 * 128;
                 laneBytes = 2 * queue_bytes(nQueue) + shadow_bytes(nQueue) + nPaths * 12 + nPaths * 4 + 4096 + nPaths * termBytes + 512 + (longRng ? nPaths * 2 * 624 * sizeof(uint32_t) + 256 : 0) +
                             (stereo ? nPaths * (12 + 6 * 8 + 6 * 4) + 16 * 256 : 0);
                 const int rc = ensure_work_or_shrink(sc, (size_t)nLanes * laneBytes + (size_t)nItems * 12 + 4096, f->spp_chunk <= 0 && (chunk > 1 || nLanes > 1));
@@ -344,7 +383,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
                     }
                     for (int b = 0; b < nBounce; b++) {
                         const QMetaRO mIn{(const FRAY_RO QMeta*)(L.meta + (b & 1))}, mSh{(const FRAY_RO QMeta*)(L.meta + 2)};
-                        const int grid = bounce_grid((size_t)nItems * cn, (ST & 2) != 0);
+                        const int grid = bounce_grid((size_t)nItems * cn, (ST & 2) != 0 && nLanes == 1);
                         hipEvent_t ea = pool_event(sc->evPool, nTraceEvents), eb = pool_event(sc->evPool, nTraceEvents + 1);
                         hipEvent_t ec = pool_event(sc->evPoolShadow, nShadowEvents), ed = pool_event(sc->evPoolShadow, nShadowEvents + 1);
                         if (!ea || !eb || !ec || !ed) return FRAYHIP_E_NOMEM;

@@ -876,3 +876,27 @@ def test_camera_angles_where_sincos_is_not_sin_and_cos(fray, abi, oracle, gpu, p
     assert np.array_equal(ids, oi) and np.array_equal(dist, od)
     assert (oi >= 0).mean() > 0.3
     s.close()
+
+
+@pytest.mark.parametrize("scene,W,H,over,fmax", [
+    ("zaphod.fray", 1920, 1080, dict(wantAA=0, dof=0), 4),             # BASELINE configs[1]: one point light, nothing draws -> no k_seed, pixel written by the kernel
+    ("zaphod.fray", 322, 215, dict(wantAA=1, dof=0), 4),               # five samples per pixel: the samples' colours go through k_pt_resolve
+    ("zaphod.fray", 200, 130, dict(wantAA=0, dof=1, numDOFSamples=7), 4),   # the lens draws: seeded
+    ("hw12/sphtri.fray", 160, 120, dict(gi=0, wantAA=0), 1024),        # three RectLights of 225 samples that draw, forced into the fused form
+    ("hw12/sphtri.fray", 90, 60, dict(gi=0, wantAA=1, stereoSeparation=0.5), 1024),   # stereo: both eyes through the one copy of the code
+])
+def test_fused_whitted_shade_is_the_wavefronts_picture(fray, abi, oracle, gpu, scene, W, H, over, fmax):
+    """Option "fused_whitted_max": k_wh_shade<ST, FUSED> (visible() in place, no queue, one launch) against the shade / visible / gather launches and the oracle."""
+    s = open_scene(fray, scene, W, H, **over)
+    s.beginRender()
+    s.set_option("fused_whitted_max", 0)
+    a, _ = s.render(seed=42)
+    assert s.get_option("whitted_path") == 1
+    s.set_option("fused_whitted_max", fmax)
+    b, st = s.render(seed=42, stats=True)
+    assert s.get_option("whitted_path") == 2 and st["shadow_launches"] == 0
+    assert np.array_equal(a, b)
+    ref, ost = oracle.render(s.desc, abi.MODE_RENDER, seed=42)
+    assert np.array_equal(b, ref)
+    assert st["shadow_rays"] == ost["shadow_rays"] and st["closest_rays"] == ost["closest_rays"]
+    s.close()

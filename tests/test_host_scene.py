@@ -391,6 +391,26 @@ def test_certified_box_test_never_contradicts_the_reference_arithmetic(tmp_path)
     assert n_true > 100000, r.stdout            # the harness must actually classify
 
 
+def test_certified_box_miss_is_never_a_hit_of_the_reference_routines(tmp_path):
+    """dev_misscert.hpp (what lets a ray that passes a CsgOp node's tree by skip CsgOp::intersect, which has no bounding volume in the reference) compiled for
+    the host: over random and adversarial rays -- grazing faces, edges and corners at offsets around the certificate's margin, starts within 1e-7 of the
+    surface and 1e4 away, directions with exact zeros -- a ray certified to miss a geometry's exact bounding box is never reported hit by the reference's own
+    Sphere::intersect, Cube::intersect or BBox::testIntersect (geometry.cpp:52-137, bbox.h:79-134, restated in the harness).  Built without the margins the
+    same harness finds contradictions by the ten thousand, so it does see them."""
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    src, inc = os.path.join(root, "tests", "native", "misscert_check.cpp"), "-I" + os.path.join(root, "fray_amd", "csrc")
+    exe = str(tmp_path / "misscert_check")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", inc, src, "-o", exe], check=True)
+    r = subprocess.run([exe, "3000000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "contradictions 0" in r.stdout, r.stdout + r.stderr
+    assert int(r.stdout.split("certified")[1].split()[0]) > 1000000, r.stdout      # the harness must actually certify
+    exe0 = str(tmp_path / "misscert_check0")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-DFRAY_MISSCERT_SCALE=0", "-DNO_HOST_MARGIN", inc, src, "-o", exe0], check=True)
+    r0 = subprocess.run([exe0, "1000000"], capture_output=True, text=True, timeout=300)
+    assert r0.returncode == 1 and int(r0.stdout.split("contradictions")[1].split()[0]) > 1000, r0.stdout
+
+
 def test_certified_triangle_filter_never_rejects_what_the_reference_accepts(tmp_path):
     """dev_tricert.hpp (the FP32 "surely misses" filter the KD leaves run before Triangle::intersectFast's arithmetic) compiled for the host: over
     adversarial rays -- aimed at edges and vertices with offsets down to 1e-17 of the triangle, grazing its plane, starting on it, from up to 1e5

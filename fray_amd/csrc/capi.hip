@@ -589,7 +589,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     for (int i = 0; i < d.n_nodes; i++) {
         DNode& N = nodes[i];
         DNodeX& X = nodesX[i];
-        N.tlTris = 0; N.tlCulling = 0; N.tlPtr = nullptr; N.boxMax = 0;
+        N.tlTris = 0; N.tlCulling = 0; N.tlPtr = nullptr; N.boxMax = 0; N.gated = 0; N.padN = 0;
         for (int k = 0; k < 3; k++) N.bmin[k] = N.bmax[k] = X.bminE[k] = X.bmaxE[k] = 0;
         if (N.geomKind == FRAYHIP_GEOM_MESH && !meshes[N.geomIndex].hasKd) {
             const DMesh& M = meshes[N.geomIndex];
@@ -650,8 +650,10 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     // gates: world-space boxes of the meshes whose brute-force triangle loops are worth skipping for a whole wave (dev_scene.hpp DGate):
     // the eight corners of the mesh's box through the node's transform (Transform::transformPoint, matrix.cpp:137-146), a hair wider
     int nGates = 0;
+    bool gatesExact = false;
     {
         DGate gates[FRAY_MAX_GATES];
+        int gateNode[FRAY_MAX_GATES];
         // ... and of the CsgOp nodes whose tree is bounded (their machine is the most expensive thing a ray can enter), unless the box is so large
         // against the others that nearly every ray enters it anyway (a floor slab): larger than 30 times the smallest such box in some extent
         double smallest = 1e300;
@@ -675,8 +677,25 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
                     g.lo[k] = std::min(g.lo[k], w); g.hi[k] = std::max(g.hi[k], w);
                 }
             }
+            // an untransformed node: the box is the geometry's own, in the space the reference tests it in -- the producers' FP32 certificate applies
+            g.exact = N.xfIdentity ? 1 : 0;
+            g.Mf = 0;
+            for (int k = 0; k < 3; k++) {
+                const double c = 0.5 * (bmin[k] + bmax[k]), half = std::max(bmax[k] - c, c - bmin[k]);
+                g.cf[k] = (float)c;
+                g.hf[k] = std::nextafterf((float)(half * (1.0 + 1e-12) + 1e-5 + std::fabs(c - (double)g.cf[k])), INFINITY);
+                g.Mf = std::max(g.Mf, std::nextafterf(std::fabs(g.cf[k]) + g.hf[k], INFINITY));
+            }
+            if (!(g.Mf < 1e9f)) g.exact = 0;
             for (int k = 0; k < 3; k++) { const double e = 1e-6 * (1.0 + std::fabs(g.lo[k]) + std::fabs(g.hi[k])); g.lo[k] -= e; g.hi[k] += e; }
+            gateNode[nGates] = i;
             gates[nGates++] = g;
+        }
+        gatesExact = nGates > 0;
+        for (int q = 0; q < nGates; q++) gatesExact = gatesExact && gates[q].exact;
+        if (gatesExact) {
+            for (int q = 0; q < nGates; q++) nodes[gateNode[q]].gated = 1;
+            memcpy(A.host.data() + oNodes, nodes.data(), nodes.size() * sizeof(DNode));        // (the nodes were copied before the gates were known)
         }
         if (nGates) memcpy(A.host.data() + oGates, gates, (size_t)nGates * sizeof(DGate));
     }
@@ -690,7 +709,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
     S.nodes = (const FRAY_RO DNode*)(base + oNodes);
     S.nodesX = (const FRAY_RO DNodeX*)(base + oNodesX);
     S.gates = (const FRAY_RO DGate*)(base + oGates);
-    S.nGates = nGates; S.padGates = 0;
+    S.nGates = nGates; S.gatesExact = gatesExact ? 1 : 0;
     S.planes = (const FRAY_RO DPlane*)(base + oPlanes);
     S.spheres = (const FRAY_RO DSphere*)(base + oSpheres);
     S.cubes = (const FRAY_RO DCube*)(base + oCubes);

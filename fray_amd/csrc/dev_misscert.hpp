@@ -53,3 +53,30 @@ FRAY_CERT_FN bool ray_surely_misses_box(double cx, double cy, double cz, double 
     miss = miss || __builtin_fabs(dx * py - dy * px) > (ay * Hx + ax * Hy) * g + pm;      // axis z: (x, y)
     return miss;
 }
+
+// The same certificate evaluated in FP32 -- what the path tracer's PRODUCERS run on every ray they emit, for every gate of the scene (kernels.hpp
+// ray_gate_class), so that a consumer may skip a gate's node for the rays filed as gate-free (a front entry of a queue segment) without testing anything.
+// The ray is the queue's own (FP64 start and direction, converted here); the box is given in FP32: centre cf = fl32(c) and half extents hf >= half +
+// 1e-5 + |c - cf|, rounded up (the host's doing).  e = 2^-24:
+//   p~ = fl32(fl32(o) - cf) is within e |o| + e |p~| of o - cf;  d~ = fl32(d) within e |d|;  so
+//   |L~ - L| <= 12 e |d|_inf (|o|_inf + |p|_inf)  and the right side's rounding stays below 4 e R:  the slack 2^-19 (omax + pmax) per unit of |d|_1 and the
+//   factor 1 + 2^-20 cover them 2.6 and 4 times; the same slack, added to H, covers test (1).  eta = 2^-21 (omax + M) >= the FP64 form's 2^-22 (|o| + M)
+//   with room for its own rounding.  `dsum` = |d~x| + |d~y| + |d~z| >= |d|_inf, so a direction that is not a unit vector (a shadow segment b - a) scales
+//   both sides alike.  A certified ray is certified by the FP64 form's conditions with margins to spare, hence misses everything in the box.
+// The harness runs both forms.
+FRAY_CERT_FN bool ray_surely_misses_box_f32(float cx, float cy, float cz, float hx, float hy, float hz, float M,
+                                            float ox, float oy, float oz, float dx, float dy, float dz, float omax, float dsum)
+{
+    const float px = ox - cx, py = oy - cy, pz = oz - cz;
+    const float pmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(px), __builtin_fabsf(py)), __builtin_fabsf(pz));
+    const float slack = (float)FRAY_MISSCERT_SCALE * 0x1p-19f * (omax + pmax);
+    const float eta = (float)FRAY_MISSCERT_SCALE * 0x1p-21f * (omax + M) + slack;
+    const float Hx = hx + eta, Hy = hy + eta, Hz = hz + eta;
+    bool miss = (px > Hx && dx >= 0) || (px < -Hx && dx <= 0) || (py > Hy && dy >= 0) || (py < -Hy && dy <= 0) || (pz > Hz && dz >= 0) || (pz < -Hz && dz <= 0);
+    const float g = 1.0f + (float)FRAY_MISSCERT_SCALE * 0x1p-20f, sl = slack * dsum;
+    const float ax = __builtin_fabsf(dx), ay = __builtin_fabsf(dy), az = __builtin_fabsf(dz);
+    miss = miss || __builtin_fabsf(dy * pz - dz * py) > (az * Hy + ay * Hz) * g + sl;
+    miss = miss || __builtin_fabsf(dx * pz - dz * px) > (az * Hx + ax * Hz) * g + sl;
+    miss = miss || __builtin_fabsf(dx * py - dy * px) > (ay * Hx + ax * Hy) * g + sl;
+    return miss;
+}

@@ -67,7 +67,7 @@ struct QMeta {
     uint32_t n;        // live paths in the queue
     uint32_t chunk;    // capacity (and stride) of one segment
     uint32_t nSeg;
-    uint32_t pad;
+    uint32_t certFront; // 1: the entries at the FRONT of the segments were certified gate-free by their producer (DScene::gatesExact); 0: a dense queue, or a hint only
     uint32_t cnt[FRAY_MAXSEG];
     uint32_t nf[FRAY_MAXSEG];
     uint32_t off[FRAY_MAXSEG + 1];

@@ -54,7 +54,8 @@ struct DNode {
     double bmin[3], bmax[3];
     const FRAY_RO DTri* tlPtr;
     double boxMax;        // max |coordinate| of bmin / bmax (margins of the certified box test, dev_boxcert.hpp)
-};                        // 264 B
+    int32_t gated, padN;  // this node's geometry lies inside an EXACT gate (DGate::exact): a ray its producer certified to miss every gate skips the node
+};                        // 272 B
 // What only the box test of the scenes WITHOUT KD meshes reads (DScene::nodesX): the node's box widened by inside()'s tolerance
 struct DNodeX {
     double bminE[3], bmaxE[3];   // bmin - 1e-6, bmax + 1e-6: what BBox::inside compares with (bbox.h:81-83), computed once on the host
@@ -168,13 +169,16 @@ struct DCamera {
 // still runs the reference's tests on every node.
 #define FRAY_MAX_GATES 8
 #define FRAY_GATE_MIN_TRIS 6
-struct DGate { double lo[3], hi[3]; };
+// exact: the gate's box is the geometry's own box in the space the reference tests it in (an untransformed node), and cf / hf / Mf are what
+// ray_surely_misses_box_f32 (dev_misscert.hpp) needs: FP32 centre, half extents widened by 1e-5 and by the centre's rounding, rounded up, and max (|cf| + hf).
+// When EVERY gate of a scene is exact (DScene::gatesExact) "gate-free" is a proof, not a hint, and the consumers skip the gated nodes for such rays.
+struct DGate { double lo[3], hi[3]; float cf[3], hf[3]; float Mf; int32_t exact; };
 
 struct DScene {
     const FRAY_RO DNode* nodes;
     const FRAY_RO DNodeX* nodesX;
     const FRAY_RO DGate* gates;
-    int32_t nGates, padGates;
+    int32_t nGates, gatesExact;
     const FRAY_RO DPlane* planes;
     const FRAY_RO DSphere* spheres;
     const FRAY_RO DCube* cubes;

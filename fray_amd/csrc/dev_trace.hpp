@@ -825,8 +825,11 @@ FD bool light_intersect(const FRAY_RO DLight& L, V3 o, V3 d, double& dist, Cnt& 
 }
 
 // The two loops of raytrace()/pathtrace(): first node wins ties (strict <), then lights.
+// gateFree: the ray's producer PROVED that it misses every gate of the scene (kernels.hpp ray_gate_class with DScene::gatesExact; dev_misscert.hpp): the
+// gated nodes' geometry then reports no intersection, as the reference computes it, and is not asked (the counting variants ask: a CsgOp node's
+// calls are part of their counters).
 template <int ST>
-FD void closest_hit(const DScene& S, V3 o, V3 d, HitT<ST>& best, Cnt& c)
+FD void closest_hit(const DScene& S, V3 o, V3 d, HitT<ST>& best, Cnt& c, bool gateFree = false)
 {
     bump<ST>(c.closest);
     best.node = -1;
@@ -840,6 +843,7 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitT<ST>& best, Cnt& c)
     for (int i = 0; i < nn; i++) {
         double dist, t, l2 = 0, l3 = 0;
         int tri = -1;
+        if constexpr (!(ST & 1)) { if (gateFree && S.nodes[i].gated) continue; }
         if constexpr ((ST & 2) != 0) {
             // Cube / CSG variants: the winning intersection as its geometry reported it travels with the hit record (finalize_hit)
             V3 ipl;
@@ -871,7 +875,7 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitT<ST>& best, Cnt& c)
 // visible(a, b), main.cpp:64-80: lights do not occlude; the first node whose (full) intersection
 // lies closer than b ends the loop.
 template <int ST>
-FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c)
+FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c, bool gateFree = false)
 {
     bump<ST>(c.shadow);
     V3 d = b - a;
@@ -887,6 +891,7 @@ FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c)
         double dist, t, l2, l3;
         int tri;
         LeafOut lo;
+        if constexpr (!(ST & 1)) { if (gateFree && S.nodes[i].gated) continue; }
         if (node_intersect<ST>(S, i, a, d, lr, dist, t, tri, l2, l3, nullptr, (ST & 2) ? &lo : nullptr, c) && dist < maxDist) return false;
     }
     return true;

@@ -869,7 +869,7 @@ static __global__ __launch_bounds__(1024) void k_scan(QMeta* m0, QMeta* m1)
 // Queue 0 of a batch is dense: a single segment that holds every slot.
 static __global__ void k_meta_dense(QMeta* m, uint32_t n)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { m->n = n; m->chunk = n; m->nSeg = 1; m->pad = 0; m->nf[0] = n; m->off[0] = 0; m->off[1] = n; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { m->n = n; m->chunk = n; m->nSeg = 1; m->certFront = 0; m->nf[0] = n; m->off[0] = 0; m->off[1] = n; }
 }
 
 // Dense index -> storage index of a segmented queue without a table in LDS: a wave walks a contiguous range of
@@ -886,13 +886,15 @@ FD uint32_t seg_first(const FRAY_RO uint32_t* off, uint32_t nSeg, uint32_t begin
     return lo;
 }
 FD uint32_t seg_slot_of(uint32_t s, uint32_t chunk, uint32_t e, uint32_t nf) { return s * chunk + (e < nf ? e : chunk - 1u - (e - nf)); }
+// `front`: the entry sits at the FRONT of its segment, i.e. its producer filed it as gate-free (bit 31 of the result; storage indices stay below 2^31).
+#define FRAY_FRONT_BIT 0x80000000u
 FD uint32_t seg_map(const FRAY_RO uint32_t* off, const FRAY_RO uint32_t* nf, uint32_t nSeg, uint32_t chunk, uint32_t base, uint32_t di, bool live, uint32_t& seg)
 {
     while (seg + 1 < nSeg && off[seg + 1] <= base) seg++;
     uint32_t i = 0, s = seg, lo = off[s];
     for (;;) {                        // the segments that overlap this batch: one, now and then two
         const uint32_t hi = off[s + 1];
-        if (live && di >= lo && di < hi) i = seg_slot_of(s, chunk, di - lo, nf[s]);
+        if (live && di >= lo && di < hi) i = seg_slot_of(s, chunk, di - lo, nf[s]) | (di - lo < nf[s] ? FRAY_FRONT_BIT : 0u);
         if (hi >= base + 64u || s + 1 >= nSeg) break;
         s++;
         lo = hi;
@@ -943,7 +945,7 @@ FD void sort_share(const FRAY_RO uint32_t* off, const FRAY_RO uint32_t* nf, uint
     for (uint32_t base = b0; base < b1; base += 64u) {
         const uint32_t di = base + lane;
         const bool live = di < b1;
-        const uint32_t i = seg_map(off, nf, nSeg, chunk, base, di, live, s1);
+        const uint32_t i = seg_map(off, nf, nSeg, chunk, base, di, live, s1) & ~FRAY_FRONT_BIT;
         if (live) atomicAdd(cnt + keyOf(i), 1u);
     }
     wave_lds_sync();
@@ -959,8 +961,8 @@ FD void sort_share(const FRAY_RO uint32_t* off, const FRAY_RO uint32_t* nf, uint
     for (uint32_t base = b0; base < b1; base += 64u) {
         const uint32_t di = base + lane;
         const bool live = di < b1;
-        const uint32_t i = seg_map(off, nf, nSeg, chunk, base, di, live, s2);
-        if (live) buf[atomicAdd(cnt + keyOf(i), 1u)] = i;
+        const uint32_t raw = seg_map(off, nf, nSeg, chunk, base, di, live, s2);     // (the front bit travels with the index)
+        if (live) buf[atomicAdd(cnt + keyOf(raw & ~FRAY_FRONT_BIT), 1u)] = raw;
     }
     seg = s2;
     wave_lds_sync();
@@ -1061,11 +1063,23 @@ FD WaveShare wave_share(uint32_t n)
 
 // Which end of its wave's queue segment a ray goes to (QMeta, dev_queues.hpp): true = it may enter one of the scene's gates (DGate: the boxes
 // of the meshes with long brute-force triangle loops).  A slab test in FP32 on the world-space box -- a scheduling hint, nothing else.
+// Round 5: when every gate of the scene is EXACT (DGate::exact: untransformed nodes) the test is dev_misscert.hpp's FP32 certificate instead, "gate-free" is
+// then proven, and the consumers skip the gated nodes for the rays filed at the front (closest_hit / visible, `gateFree`).
 FD bool ray_gate_class(const DScene& S, V3 o, V3 d)
 {
     const int ng = S.nGates;
     if (ng == 0) return false;
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    if (S.gatesExact) {
+        const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+        const float omax = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)), dsum = fabsf(dx) + fabsf(dy) + fabsf(dz);
+        bool any = false;
+        for (int g = 0; g < ng; g++) {
+            const FRAY_RO DGate& G = S.gates[g];
+            any = any || !ray_surely_misses_box_f32(G.cf[0], G.cf[1], G.cf[2], G.hf[0], G.hf[1], G.hf[2], G.Mf, ox, oy, oz, dx, dy, dz, omax, dsum);
+        }
+        return any || !(omax < 1e9f);
+    }
     const float rx = __builtin_amdgcn_rcpf((float)d.x), ry = __builtin_amdgcn_rcpf((float)d.y), rz = __builtin_amdgcn_rcpf((float)d.z);
     bool any = false;
     for (int g = 0; g < ng; g++) {
@@ -1198,6 +1212,7 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
     const FRAY_RO uint32_t* off = FIRST ? nullptr : metaIn.p->off;
     const FRAY_RO uint32_t* nfIn = FIRST ? nullptr : metaIn.p->nf;
     const uint32_t nSeg = FIRST ? 1u : metaIn.p->nSeg, chunkIn = FIRST ? A.FA.n : metaIn.p->chunk;
+    const bool certFront = !FIRST && metaIn.p->certFront != 0;
     const WaveShare ws = wave_share(FIRST ? A.FA.n : metaIn.p->n);
     const uint32_t lane = threadIdx.x & 63u;
     SegEnds outEnds{ws.begin, ws.chunk, 0, 0};                                            // wave-uniform
@@ -1231,7 +1246,7 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
         const StereoBuf& SB = KARG(BounceArgs, AP, SB);
         const LongRng& LR = KARG(BounceArgs, AP, LR);
         const uint32_t di = base + lane;
-        bool cont = false, shadow = false, shadowBack = false;
+        bool cont = false, shadow = false, shadowBack = false, gateFree = false;
         PathStateT<G> ps;
         bool live = di < b1;
         uint32_t i = di, seed0 = 0;
@@ -1252,6 +1267,8 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
         } else {
             if constexpr (SORT) i = live ? sorted[di - b0] : 0u;
             else i = seg_map(off, nfIn, nSeg, chunkIn, base, di, live, seg);
+            gateFree = certFront && (i & FRAY_FRONT_BIT);
+            i &= ~FRAY_FRONT_BIT;
             if (live) {
                 path_load_ray(Qin, i, ps);
                 live = !(ps.d.x == 0 && ps.d.y == 0 && ps.d.z == 0);            // k_pt_init's mark of a slot without a path
@@ -1261,7 +1278,7 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
             STAMP(0);
             // entry test of pathtrace() (main.cpp:173-176) was applied before this path was queued
             HitT<ST> h;
-            closest_hit<ST>(S, ps.o, ps.d, h, c);
+            closest_hit<ST>(S, ps.o, ps.d, h, c, gateFree);
             if constexpr (FIRST) {
                 // the rest of the path's state, made after the search so that it is not live across it: the generators stand where the camera ray left them
                 ps.pm = c3(1, 1, 1); ps.slot = di; ps.depth = 0; ps.flags = 0;
@@ -1311,7 +1328,10 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
         metaOut->cnt[ws.w] = outEnds.nF + outEnds.nB; metaOut->nf[ws.w] = outEnds.nF;
         metaShadow->cnt[ws.w] = shadowCount[threadIdx.x >> 6][0] + shadowCount[threadIdx.x >> 6][1]; metaShadow->nf[ws.w] = shadowCount[threadIdx.x >> 6][0];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { metaOut->chunk = ws.chunk; metaOut->nSeg = ws.W; metaShadow->chunk = ws.chunk; metaShadow->nSeg = ws.W; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        metaOut->chunk = ws.chunk; metaOut->nSeg = ws.W; metaShadow->chunk = ws.chunk; metaShadow->nSeg = ws.W;
+        metaOut->certFront = metaShadow->certFront = A.S.gatesExact ? 1u : 0u;          // what ray_gate_class filed at the front is proven gate-free
+    }
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
 }
@@ -1328,6 +1348,7 @@ static __global__ __launch_bounds__(256, anyhit_waves(ST)) void k_pt_shadow(Shad
     const FRAY_RO uint32_t* off = meta.p->off;
     const FRAY_RO uint32_t* nfIn = meta.p->nf;
     const uint32_t nSeg = meta.p->nSeg, chunkIn = meta.p->chunk;
+    const bool certFront = meta.p->certFront != 0;
     const WaveShare ws = wave_share(meta.p->n);
     const uint32_t lane = threadIdx.x & 63u;
     if (ws.begin >= ws.end) return;
@@ -1357,11 +1378,13 @@ static __global__ __launch_bounds__(256, anyhit_waves(ST)) void k_pt_shadow(Shad
         uint32_t i;
         if constexpr (SORT) i = live ? sorted[di - b0] : 0u;
         else i = seg_map(off, nfIn, nSeg, chunkIn, base, di, live, seg);
+        const bool gateFree = certFront && (i & FRAY_FRONT_BIT);
+        i &= ~FRAY_FRONT_BIT;
         if (live) {
             const ShadowRec* const r = SQ.rec + i;
             const V3 a = v3(r->a[0], r->a[1], r->a[2]), b = v3(r->b[0], r->b[1], r->b[2]);
             STAMP(0);
-            const bool vis = visible<ST>(S, a, b, c);
+            const bool vis = visible<ST>(S, a, b, c, gateFree);
             const uint32_t sl = r->slot;
 #ifdef FRAY_QCHECK
             // diagnostic build: an entry whose slot is not a slot of this batch was never written by the bounce kernel (or was consumed before): count it

@@ -207,6 +207,7 @@ def main():
                     help="exact (default): the reference's arithmetic everywhere, every pixel the oracle's bit for bit.  contracted: option fp_contract = 1 for the timed region "
                     "(path tracing past a sample's first closest hit on kernels built with fused multiply-adds; colour within 1e-4 RMS).  The default run reports the "
                     "contracted figures too, in a `contracted` object beside the exact line")
+    ap.add_argument("--no-contracted", action="store_true", help="skip the second timed region that renders the same frame with option fp_contract = 1 (profiling passes: one arithmetic per run)")
     ap.add_argument("--library-gather", action="store_true", help="with --backend gloo: still exchange through frayhip_gather_buckets (the library binds whatever RCCL "
                     "FRAYHIP_RCCL_LIBRARY names -- on a one-GPU box the test suite's loopback stand-in, since RCCL itself refuses two ranks on one device)")
     args = ap.parse_args()
@@ -415,7 +416,7 @@ def main():
     # counted by its own instrumented pass, and kept for the parity figures of cpu_baseline below.  The default line stays the exact one.
     contracted = None
     exact_frame = frame
-    if rank == 0 and world == 1 and scene.settings.gi and mode == abi.MODE_RENDER and args.arith == "exact" and args.shard_of <= 1:
+    if rank == 0 and world == 1 and scene.settings.gi and mode == abi.MODE_RENDER and args.arith == "exact" and args.shard_of <= 1 and not args.no_contracted:
         exact_frame = frame.clone()
         scene.set_option("fp_contract", 1)
         st_c = step(stats=True)
@@ -519,13 +520,14 @@ def main():
         # Counter-derived figures (HBM traffic, VALU issue and lane utilisation) cannot be collected by this process: they come
         # from rocprofv3 --pmc passes of this same command (tools/profile_workload.sh -> profiles/pmc_latest_<workload>.json) and are
         # printed only when that profile was taken on the same device code (source hash) and workload; otherwise they stay null.
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest_%s.json" % args.workload)
-        if not os.path.exists(pmc_path):
+        pmc_key = args.workload + ("_contracted" if args.arith == "contracted" else "")       # tools/profile_workload.sh profiles one arithmetic per run
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest_%s.json" % pmc_key)
+        if not os.path.exists(pmc_path) and args.arith == "exact":
             pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if world == 1 and os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
-                if pmc.get("source_hash") == src and pmc.get("workload") == args.workload:
+                if pmc.get("source_hash") == src and pmc.get("workload") == pmc_key:
                     for key in ("roofline", "roofline_shadow_kernel", "roofline_shade_kernel"):
                         k = pmc["kernels"].get(out[key]["kernel"]) if key in out else None
                         # per-launch figures only describe launches of the profiled size (another queue budget cuts the frame into other launches)
@@ -551,6 +553,18 @@ def main():
                 pass
         cframe = contracted.pop("frame") if contracted else None
         if contracted:
+            # vector instructions per 64-ray iteration of the bounce kernel in both arithmetics, from the two kept counter profiles (same source hash only)
+            try:
+                pe = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest_%s.json" % args.workload)))
+                pc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest_%s_contracted.json" % args.workload)))
+                if pe.get("source_hash") == src and pc.get("source_hash") == src:
+                    for kname in ("k_pt_bounce", "k_pt_shadow"):
+                        a, b = pe["kernels"][kname]["per_launch"], pc["kernels"][kname]["per_launch"]
+                        contracted.setdefault("valu_wave_instructions_per_launch", {})[kname] = {"exact": a["SQ_INSTS_VALU"], "contracted": b["SQ_INSTS_VALU"],
+                                                                                                "ratio": b["SQ_INSTS_VALU"] / a["SQ_INSTS_VALU"]}
+                        contracted.setdefault("avg_launch_ms", {})[kname] = {"exact": pe["kernels"][kname].get("avg_launch_ms"), "contracted": pc["kernels"][kname].get("avg_launch_ms")}
+            except (KeyError, ValueError, OSError, ZeroDivisionError):
+                pass
             d = (cframe.double() - exact_frame.double())
             contracted["vs_exact_frame"] = {"rms_per_channel": [float(v) for v in (d ** 2).mean(dim=(0, 1)).sqrt().cpu()], "max_abs": float(d.abs().max()),
                                             "bit_identical_pixels": float((cframe == exact_frame).all(dim=2).float().mean())}

@@ -204,23 +204,23 @@ FD void light_nth_sample(const FRAY_RO DLight& L, int idx, V3 shadePos, G& tab, 
         color = ldc(L.color) * L.power;
         return;
     }
-    int column = idx % L.xSubd;
+    int col = idx % L.xSubd;
     int row = idx / L.xSubd;
-    double areaXsize = L.areaXsize;
-    double areaYsize = L.areaYsize;
-    double areaXstart = column * areaXsize;
-    double areaYstart = row * areaYsize;
-    double p_x = areaXstart + areaXsize * rng_float(tab);
-    double p_y = areaYstart + areaYsize * rng_float(tab);
-    V3 pointOnLight = v3(p_x - 0.5, 0, p_y - 0.5);
+    double cellW = L.areaXsize;
+    double cellH = L.areaYsize;
+    double x0 = col * cellW;
+    double y0 = row * cellH;
+    double p_x = x0 + cellW * rng_float(tab);
+    double p_y = y0 + cellH * rng_float(tab);
+    V3 pl = v3(p_x - 0.5, 0, p_y - 0.5);
     V3 sp = mulM(shadePos - ld3(L.T.off), L.T.inv);
     if (sp.y > 0) {
         color = c3(0, 0, 0);
     } else {
-        float cosWeight = float(fray_div(dot(v3(0, -1, 0), sp), length(sp)));
-        color = ldc(L.color) * L.power * (float)L.area * cosWeight;
+        float cw = float(fray_div(dot(v3(0, -1, 0), sp), length(sp)));
+        color = ldc(L.color) * L.power * (float)L.area * cw;
     }
-    samplePos = mulM(pointOnLight, L.T.m) + ld3(L.T.off);
+    samplePos = mulM(pl, L.T.m) + ld3(L.T.off);
 }
 FD double light_solid_angle(const FRAY_RO DLight& L, V3 ip)
 {
@@ -245,20 +245,20 @@ FD C3 shade_direct(const DScene& S, const FRAY_RO DShader& sh, V3 rayDir, const 
             C3 lc;
             V3 lp;
             light_nth_sample(L, k, info.ip, tab, lp, lc);
-            double lightDistSqr = lengthSqr(info.ip - lp);
-            V3 toLight = normalized(lp - info.ip);
+            double d2 = lengthSqr(info.ip - lp);
+            V3 wl = normalized(lp - info.ip);
             V3 n = faceforward(rayDir, info.norm);
-            float cosAngle = (float)dot(toLight, n);
-            float lambertTerm = (float)(cosAngle / lightDistSqr);
-            lambertTerm = lambertTerm > 0.0f ? lambertTerm : 0.0f;   // max(0.0f, x)
+            float cosN = (float)dot(wl, n);
+            float lam = (float)(cosN / d2);
+            lam = lam > 0.0f ? lam : 0.0f;   // max(0.0f, x)
             if (visible<ST>(S, info.ip + n * 1e-6, lp, c)) {
-                C3 r = diffuse * lc * lambertTerm;
+                C3 r = diffuse * lc * lam;
                 if (phong) {
-                    V3 fromLight = -toLight;
-                    V3 rr = reflect(fromLight, n);
-                    double cosCam = dot(-rayDir, rr);
-                    if (cosCam > 0)
-                        r = r + lc / (float)lightDistSqr * ldc(sh.specularColor) * (float)pow(cosCam, sh.exponent) * (float)sh.specularMultiplier;
+                    V3 wi = -wl;
+                    V3 rr = reflect(wi, n);
+                    double cosV = dot(-rayDir, rr);
+                    if (cosV > 0)
+                        r = r + lc / (float)d2 * ldc(sh.specularColor) * (float)pow(cosV, sh.exponent) * (float)sh.specularMultiplier;
                 }
                 sum = sum + r;
             }
@@ -361,13 +361,13 @@ FD bool nee_prepare(const DScene& S, V3 rayDir, const HitInfo& info, C3 pm, cons
     double solidAngle = light_solid_angle(L, x);
     if (solidAngle == 0) return false;
     int randSample = rng_int0(rnd, light_num_samples(L) - 1);
-    V3 pointOnLight;
+    V3 pl;
     C3 unused;
-    light_nth_sample(L, randSample, x, tab, pointOnLight, unused);
+    light_nth_sample(L, randSample, x, tab, pl, unused);
     a = x + info.norm * 1e-6;
-    b = pointOnLight;
+    b = pl;
     C3 Le = light_color(L);
-    V3 w_out = normalized(pointOnLight - x);
+    V3 w_out = normalized(pl - x);
     C3 brdfAtPoint = brdf_eval(sh, info, w_out);
     if (intensity(brdfAtPoint) == 0) { contrib = c3(0, 0, 0); return true; }
     float probHitLightArea = (float)fray_rcp(solidAngle);

@@ -591,18 +591,18 @@ FD void wh_shade_eye(const DScene& S, V3 o, V3 d, MtLong& tab, const WhittedQueu
                     C3 lc;
                     V3 lp;
                     light_nth_sample(L, k, info.ip, tab, lp, lc);
-                    double lightDistSqr = lengthSqr(info.ip - lp);
-                    V3 toLight = normalized(lp - info.ip);
-                    float cosAngle = (float)dot(toLight, n);
-                    float lambertTerm = (float)(cosAngle / lightDistSqr);
-                    lambertTerm = lambertTerm > 0.0f ? lambertTerm : 0.0f;   // max(0.0f, x)
-                    C3 r = diffuse * lc * lambertTerm;
+                    double d2 = lengthSqr(info.ip - lp);
+                    V3 wl = normalized(lp - info.ip);
+                    float cosN = (float)dot(wl, n);
+                    float lam = (float)(cosN / d2);
+                    lam = lam > 0.0f ? lam : 0.0f;   // max(0.0f, x)
+                    C3 r = diffuse * lc * lam;
                     if (phong) {
-                        V3 fromLight = -toLight;
-                        V3 rr = reflect(fromLight, n);
-                        double cosCam = dot(-d, rr);
-                        if (cosCam > 0)
-                            r = r + lc / (float)lightDistSqr * ldc(sh.specularColor) * (float)pow(cosCam, sh.exponent) * (float)sh.specularMultiplier;
+                        V3 wi = -wl;
+                        V3 rr = reflect(wi, n);
+                        double cosV = dot(-d, rr);
+                        if (cosV > 0)
+                            r = r + lc / (float)d2 * ldc(sh.specularColor) * (float)pow(cosV, sh.exponent) * (float)sh.specularMultiplier;
                     }
                     if constexpr (FUSED) {
                         if (visible<ST>(S, a, lp, c)) sum = sum + r;

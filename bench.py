@@ -476,7 +476,9 @@ def main():
                        "speculative_fans": {k: scene.get_option(k) for k in ("fans_filed", "fan_children", "fan_children_looked_up", "fans_given_up")}},
             # What bounds the dominant kernel is FP64 vector issue, not HBM: algorithmic FP64
             # operations per launch (SURVEY 8d operation counts x this frame's work counters) / average launch duration.
-            "roofline": {"bound": "fp64_valu", "kernel": kern, "achieved": tf, "peak": FP64_PEAK, "unit": "TFLOP/s", "frac": tf / FP64_PEAK,
+            "roofline": {"why_not_hbm": "the contract's HBM roofline does not bound this path: SURVEY 8(d)'s algorithmic bytes are node transforms and triangle records that the scalar cache serves "
+                                        "(roofline_hbm.frac comes out ABOVE 1), measured HBM traffic is `traffic` (about 0.2 of peak); what bounds the kernels is FP64 vector issue",
+                         "bound": "fp64_valu", "kernel": kern, "achieved": tf, "peak": FP64_PEAK, "unit": "TFLOP/s", "frac": tf / FP64_PEAK,
                          "alg_flops_per_launch": flops_per_launch, "avg_launch_ms": avg_launch_ms, "launches_per_step": tr_n,
                          "sum_launch_ms_per_step": tr_ms,
                          "durations_from": ("serialised pass (pt_lanes = 1), %.2f ms per frame%s" % (serial["ms_per_step"], (": " + serial_note) if serial_note else "")) if serial else "the timed region",

@@ -11,6 +11,9 @@
 // is entered (the tests are pure functions of the ray); "which child first" is ray.start[axis] < split, so the visiting order, the outcome
 // of every box test, the triangles tested and the first accepted leaf are exactly the reference's.
 #pragma once
+#ifndef FRAY_IDENTITY_SKIP
+#define FRAY_IDENTITY_SKIP 1       // node_intersect: untransformed nodes skip v * I (round 5)
+#endif
 #ifndef FRAY_FILTER_STRAIGHT
 #define FRAY_FILTER_STRAIGHT 1     // see mesh_intersect's leaf loop
 #endif
@@ -39,6 +42,8 @@ constexpr bool kd_variant(int st) { return (st & 6) != 0; }
 // bit 3 = the scene has textures (bitmap, checker, Fresnel, bump) or a loaded environment map; the variants without it (and without bits 1 / 2,
 // which imply it) are compiled without texture sampling, bump mapping, the cubemap lookup and the sphere's uv (atan2 / asin)
 constexpr bool tex_variant(int st) { return (st & 14) != 0; }
+// the variants whose node_intersect takes the shortcut for untransformed nodes (flag words 0 and 1)
+constexpr bool identity_variant(int st) { return FRAY_IDENTITY_SKIP && (st & 14) == 0; }
 
 // Closest-hit record.  Shading attributes (ip, normal, uv, dNdx/dNdy) are re-derived from it for
 // the winning node only (finalize_hit in dev_shade.hpp) -- same arithmetic, so same bits.
@@ -768,19 +773,22 @@ FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double&
         // An untransformed node (offset 0, m = invM = I, bit for bit: cornell_box's seven meshes): v * I is v.x * 1 + v.y * 0 + v.z * 0 = v.x exactly whenever
         // v.x is not a zero (then the sum's sign of zero would depend on the other components), so the two 15-operation products are skipped unless some lane
         // of the wave holds an exact zero; the normalisation is the reference's.
+        // Only in the leanest variants (identity_variant: no KD walk, no texture code -- cornell_box's): beside the KD walk the extra test cost the any-hit
+        // kernel a fifth of its speed (boxed Whitted 6.97 -> 8.45 ms, forest DOF 16 10.0 -> 10.6: registers in the walk's loop), and in the textured
+        // variants, whose scenes (smallpt: translated planes and spheres) have no such node, its mere presence 3 % of k_whitted (3.12 -> 3.22 ms).
+        bool done = false;
+        if constexpr (identity_variant(ST)) {
 #if FRAY_ARITH
-        // (relaxed arithmetic: the directions the path tracer makes are unit vectors to an ulp: no second normalisation, no zero check)
-        if (N.xfIdentity) {
-            lr.s = o;
-            lr.d = d;
-        } else {
+            // (relaxed arithmetic: the directions the path tracer makes are unit vectors to an ulp: no second normalisation, no zero check)
+            if (N.xfIdentity) { lr.s = o; lr.d = d; done = true; }
 #else
-        const bool zeros = o.x == 0 || o.y == 0 || o.z == 0 || d.x == 0 || d.y == 0 || d.z == 0;
-        if (N.xfIdentity && !__any(zeros)) {
-            lr.s = o;
-            lr.d = normalized(d);
-        } else {
+            if (N.xfIdentity) {                     // (wave-uniform: a transformed node pays nothing for the test below)
+                const bool zeros = o.x == 0 || o.y == 0 || o.z == 0 || d.x == 0 || d.y == 0 || d.z == 0;
+                if (!__any(zeros)) { lr.s = o; lr.d = normalized(d); done = true; }
+            }
 #endif
+        }
+        if (!done) {
             lr.s = mulM(o - ld3(N.T.off), N.T.inv);
             lr.d = normalized(mulM(d, N.T.inv));
         }
@@ -794,11 +802,16 @@ FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double&
     if (!hit) return false;
     if constexpr ((ST & 2) != 0) { if (iplOut) *iplOut = ipl; }
     // (an untransformed node: ipl * I + 0 is ipl up to the sign of a zero, which the squares below do not see)
+    V3 ipw;
+    if constexpr (identity_variant(ST)) {
 #if FRAY_ARITH
-    // (relaxed arithmetic: along a unit direction in world space the ray parameter IS the distance -- planes, spheres, triangles; a Cube / CsgOp reports a length already)
-    if (N.xfIdentity) { dist = t; STAMP(6); return true; }
+        // (relaxed arithmetic: along a unit direction in world space the ray parameter IS the distance -- planes, spheres, triangles)
+        if (N.xfIdentity) { dist = t; STAMP(6); return true; }
 #endif
-    V3 ipw = N.xfIdentity ? ipl : mulM(ipl, N.T.m) + ld3(N.T.off);
+        ipw = N.xfIdentity ? ipl : mulM(ipl, N.T.m) + ld3(N.T.off);
+    } else {
+        ipw = mulM(ipl, N.T.m) + ld3(N.T.off);
+    }
     dist = length(o - ipw);
     STAMP(6);
     return true;
@@ -840,10 +853,11 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitT<ST>& best, Cnt& c, bool ga
     LocalRay lr;
     lr.cls = -1;
     lr.haveRd = false;
+    const bool anyGateFree = !(ST & 1) && __any(gateFree);           // wave-uniform: without such a lane the nodes' `gated` words are not even read
     for (int i = 0; i < nn; i++) {
         double dist, t, l2 = 0, l3 = 0;
         int tri = -1;
-        if constexpr (!(ST & 1)) { if (gateFree && S.nodes[i].gated) continue; }
+        if (anyGateFree && gateFree && S.nodes[i].gated) continue;
         if constexpr ((ST & 2) != 0) {
             // Cube / CSG variants: the winning intersection as its geometry reported it travels with the hit record (finalize_hit)
             V3 ipl;
@@ -887,11 +901,12 @@ FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c, bool gateFree = false)
     LocalRay lr;
     lr.cls = -1;
     lr.haveRd = false;
+    const bool anyGateFree = !(ST & 1) && __any(gateFree);
     for (int i = 0; i < nn; i++) {
         double dist, t, l2, l3;
         int tri;
         LeafOut lo;
-        if constexpr (!(ST & 1)) { if (gateFree && S.nodes[i].gated) continue; }
+        if (anyGateFree && gateFree && S.nodes[i].gated) continue;
         if (node_intersect<ST>(S, i, a, d, lr, dist, t, tri, l2, l3, nullptr, (ST & 2) ? &lo : nullptr, c) && dist < maxDist) return false;
     }
     return true;

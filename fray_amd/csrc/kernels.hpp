@@ -797,7 +797,8 @@ FD uint32_t ray_sort_class(V3 d, bool gate)
     const uint32_t g = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
     return (g ^ (g >> 1) ^ (g >> 2)) | (gate ? 8u : 0u);
 }
-template <class G>
+// STORE_CLS: only the variants whose consumers sort (sort_variant) read the class array
+template <bool STORE_CLS, class G>
 FD void path_store(const PathQueue& Q, uint32_t i, const PathStateT<G>& s, uint32_t cls)
 {
     PathRec* r = Q.rec + i;
@@ -809,8 +810,7 @@ FD void path_store(const PathQueue& Q, uint32_t i, const PathStateT<G>& s, uint3
     const Mt &g = cursor(s.rnd), &t = cursor(s.tab);
     r->rnd[0] = g.j; r->rnd[1] = g.a; r->rnd[2] = g.b;
     r->tab[0] = t.j; r->tab[1] = t.a; r->tab[2] = t.b;
-    r->pad = 0;
-    Q.cls[i] = (unsigned char)cls;
+    if constexpr (STORE_CLS) Q.cls[i] = (unsigned char)cls;
 }
 template <class G>
 FD void path_load_ray(const PathQueue& Q, uint32_t i, PathStateT<G>& s)
@@ -1032,13 +1032,13 @@ static __global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFr
             ps.depth = 0;
             ps.flags = 0;
             bump<ST>(c.samples);
-            path_store(Q, slot, ps, ray_sort_class(ps.d, false));
+            path_store<FRAY_SORT && sort_variant(ST)>(Q, slot, ps, ray_sort_class(ps.d, false));
         } else {
             // no path in this slot: a zero direction says so to the bounce kernel (which then needs no load beyond the ray's own 48 bytes to know)
             PathRec* r = Q.rec + slot;
             r->d[0] = 0; r->d[1] = 0; r->d[2] = 0;
             r->depthFlags = FRAY_DEAD;
-            Q.cls[slot] = 15;               // sorted last
+            if constexpr (FRAY_SORT && sort_variant(ST)) Q.cls[slot] = 15;               // sorted last
         }
         termCount[slot] = 0;
     }
@@ -1159,7 +1159,7 @@ FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitT<ST>& h, const 
                 r->b[0] = sb.x; r->b[1] = sb.y; r->b[2] = sb.z;
                 r->c[0] = sc.r; r->c[1] = sc.g; r->c[2] = sc.b;
                 r->slot = ps.slot;
-                SQ.cls[j] = (unsigned char)ray_sort_class(sb - sa, shadowBack);
+                if constexpr (FRAY_SORT && sort_variant(ST)) SQ.cls[j] = (unsigned char)ray_sort_class(sb - sa, shadowBack);
             }
         }
         PathRay win, wout;
@@ -1313,9 +1313,9 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
         const bool back = cont && ray_gate_class(S, ps.o, ps.d);
         const uint32_t slotOut = seg_slot(outEnds, cont, back);
 #ifdef FRAY_SORT_BY_MATERIAL
-        if (cont) path_store(Qout, slotOut, ps, (ps.flags >> 8) & 3u);
+        if (cont) path_store<true>(Qout, slotOut, ps, (ps.flags >> 8) & 3u);
 #else
-        if (cont) path_store(Qout, slotOut, ps, ray_sort_class(ps.d, back));
+        if (cont) path_store<FRAY_SORT && sort_variant(ST)>(Qout, slotOut, ps, ray_sort_class(ps.d, back));
 #endif
         seg_advance(outEnds, cont, back);
         STAMP(13);

@@ -268,7 +268,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             // lights.cpp:62-63).  Up to 227 the generators are three registers; beyond that every path gets two 624-word columns (MtPath).
             const bool longRng = 8 + 10 * (set.maxTraceDepth + 2) > 227;
             const size_t termBytes = (size_t)(set.maxTraceDepth + 2) * 12 + 2;       // one FP32 RGB term per bounce and sample, and their count
-            const size_t perPath = 280 + termBytes + (longRng ? 2 * 624 * sizeof(uint32_t) : 0);
+            const size_t perPath = 240 + termBytes + (longRng ? 2 * 624 * sizeof(uint32_t) : 0);
             // Batches of `chunk` samples per pixel; up to FRAY_PT_LANES batches are in flight at once, each on its own
             // stream with its own queues, so one batch's launch gaps, scans and kernel tails are filled by the others'
             // blocks.  Only the resolves are ordered (evResolved): the per-pixel sum runs in sample order.

@@ -424,7 +424,7 @@ int frayhip_scene_create(const frayhip_scene_desc* desc, frayhip_scene** out)
         csgs[i].op = g.op;
         csgs[i].leftKind = d.geoms[g.left].kind; csgs[i].leftIndex = d.geoms[g.left].index; csgs[i].leftGeom = g.left;
         csgs[i].rightKind = d.geoms[g.right].kind; csgs[i].rightIndex = d.geoms[g.right].index; csgs[i].rightGeom = g.right;
-        csgs[i].pad = 0;
+        csgs[i].flat = (csgs[i].leftKind <= FRAYHIP_GEOM_CUBE && csgs[i].rightKind <= FRAYHIP_GEOM_CUBE) ? 1 : 0;
     }
     size_t oCsgs = A.add(csgs.data(), csgs.size() * sizeof(DCsg));
     // meshes

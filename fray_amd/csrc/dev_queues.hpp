@@ -63,7 +63,7 @@ struct TermBuf {
 // front, the others from the back.  cnt[w] = entries of wave w's segment, nf[w] = how many of them sit at the front; entry e of the segment
 // (dense order: the front ones in order, then the back ones, last written first) lives at w * chunk + (e < nf ? e : chunk - 1 - (e - nf))
 // (seg_slot_of, kernels.hpp).  (Two table entries per segment -- front run, back run -- measured +0.2 ms per launch at 8192 segments.)
-struct QMeta {
+struct alignas(256) QMeta {
     uint32_t n;        // live paths in the queue
     uint32_t chunk;    // capacity (and stride) of one segment
     uint32_t nSeg;

@@ -69,7 +69,7 @@ struct DNodeX {
 struct DPlane { double limit, height; };
 struct DSphere { double O[3]; double R; };
 struct DCube { double O[3]; double halfSide; };
-struct DCsg { int32_t op, leftKind, leftIndex, rightKind, rightIndex, leftGeom, rightGeom, pad; };   // kinds/indices as in DNode
+struct DCsg { int32_t op, leftKind, leftIndex, rightKind, rightIndex, leftGeom, rightGeom, flat; };   // kinds/indices as in DNode; flat: both operands are planes / spheres / cubes (csg_flat_intersect)
 
 struct DTri {          // 128 B
     double g[3];       // gnormal

@@ -654,6 +654,110 @@ FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win
     }
 }
 
+// ---- CsgOp over two PLAIN operands (plane / sphere / cube: DCsg::flat) without the machine ---------------------------
+// The same calls in the same order on the same rays as csg_intersect makes for such a node -- findAllIntersections on the left operand, on the right
+// operand, the sorted walk, the winner's chain again (geometry.cpp:139-194) -- with everything in registers: a convex operand is crossed twice, so four
+// distances per operand are kept; a chain that finds a fifth intersection, or whose distances do not come out in non-decreasing order, sets `fallback` and
+// the node goes through the general machine, which computes the same answer.  The order of the (at most eight) distances: libstdc++'s std::sort of up to
+// sixteen elements is its final insertion sort alone (bits/stl_algo.h __final_insertion_sort: strict comparisons, equal elements keep their order), i.e. a
+// stable merge of the two chains in which the left operand's entries come first among equals -- what the loop below walks.
+// (csg_nested.fray, bokeh.fray: the floor every ray of the scene asks is Cube - Cube.)
+FD double sel4(double a0, double a1, double a2, double a3, int i) { return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); }
+template <int ST>
+FD bool prim_intersect_plain(const DScene& S, int kind, int index, V3 s, V3 d, GHit& h, Cnt& c)
+{
+    h.code = -1; h.l2 = 0; h.l3 = 0;
+    bump<ST>(c.prim);
+    if (kind == 0) {
+        const FRAY_RO DPlane& P = S.planes[index];
+        if (s.y > P.height && d.y >= 0) return false;
+        if (s.y < P.height && d.y <= 0) return false;
+        double scaling = fray_div(fabs(s.y - P.height), fabs(d.y));
+        V3 ip = s + d * scaling;
+        if (fabs(ip.x) > P.limit) return false;
+        if (fabs(ip.z) > P.limit) return false;
+        h.ip = ip;
+        h.dist = length(s - ip);
+        return true;
+    }
+    if (kind == 1) {
+        const FRAY_RO DSphere& Sp = S.spheres[index];
+        V3 H = s - ld3(Sp.O);
+        double B = 2 * dot(d, H);
+        double C = lengthSqr(H) - Sp.R * Sp.R;
+        double Disc = B * B - 4 * 1 * C;
+        if (Disc < 0) return false;
+        double sq = fray_sqrt(Disc);
+        double p1 = (-B + sq) / (2 * 1.0), p2 = (-B - sq) / (2 * 1.0);
+        double smaller = p2 < p1 ? p2 : p1, larger = p1 < p2 ? p2 : p1;
+        if (larger < 0) return false;
+        double dd = (smaller >= 0) ? smaller : larger;
+        h.ip = s + d * dd;
+        h.dist = length(s - h.ip);
+        return true;
+    }
+    return cube_intersect(S.cubes[index], s, d, h);
+}
+template <int ST>
+FD bool csg_flat_intersect(const DScene& S, const FRAY_RO DCsg& G, V3 s, V3 d, GHit& win, bool& fallback, Cnt& c)
+{
+    fallback = false;
+    double l0 = 0, l1 = 0, l2 = 0, l3 = 0, r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    int nl = 0, nr = 0;
+    // pass 0: findAllIntersections (geometry.cpp:144-158) on the left, then on the right operand
+    for (int op = 0; op < 2; op++) {
+        const int kind = op == 0 ? G.leftKind : G.rightKind, index = op == 0 ? G.leftIndex : G.rightIndex;
+        V3 start = s;
+        int k = 0;
+        for (;;) {
+            GHit h;
+            if (!prim_intersect_plain<ST>(S, kind, index, start, d, h, c)) break;
+            if (k == 4) { fallback = true; break; }
+            const double dist = k > 0 ? length(h.ip - s) : h.dist;           // geometry.cpp:155-156
+            if (op == 0) { l0 = k == 0 ? dist : l0; l1 = k == 1 ? dist : l1; l2 = k == 2 ? dist : l2; l3 = k == 3 ? dist : l3; }
+            else { r0 = k == 0 ? dist : r0; r1 = k == 1 ? dist : r1; r2 = k == 2 ? dist : r2; r3 = k == 3 ? dist : r3; }
+            k++;
+            start = h.ip + d * 1e-6;
+        }
+        if (op == 0) nl = k; else nr = k;
+    }
+    // a chain out of order (never seen; NaNs included) leaves the insertion sort's result to the general machine
+    const bool sortedL = (nl < 2 || l0 <= l1) && (nl < 3 || l1 <= l2) && (nl < 4 || l2 <= l3);
+    const bool sortedR = (nr < 2 || r0 <= r1) && (nr < 3 || r1 <= r2) && (nr < 4 || r2 <= r3);
+    if (!(sortedL && sortedR)) fallback = true;
+    if (fallback) return false;
+    // the walk over the sorted intersections (geometry.cpp:160-185)
+    bool inL = (nl & 1) == 1, inR = (nr & 1) == 1;
+    auto bop = [&](bool l, bool r) { return G.op == 0 ? (l || r) : (G.op == 1 ? (l && r) : (l && !r)); };
+    const bool cur = bop(inL, inR);
+    int i = 0, j = 0, winOp = -1, winK = 0;
+    double winDist = 0;
+    while (winOp < 0 && (i < nl || j < nr)) {
+        const double dl = sel4(l0, l1, l2, l3, i), dr = sel4(r0, r1, r2, r3, j);
+        const bool takeL = j >= nr || (i < nl && !(dr < dl));       // equal distances: the left operand's entry stands first (stable)
+        if (takeL) inL = !inL; else inR = !inR;
+        if (bop(inL, inR) != cur) { winOp = takeL ? 0 : 1; winK = takeL ? i : j; winDist = takeL ? dl : dr; }
+        if (takeL) i++; else j++;
+    }
+    if (winOp < 0) return false;
+    // pass 1: the winner's record, by walking its operand's chain again (the same calls on the same rays; not counted twice)
+    const int kind = winOp == 0 ? G.leftKind : G.rightKind, index = winOp == 0 ? G.leftIndex : G.rightIndex;
+    const Cnt keep = c;
+    V3 start = s;
+    GHit h;
+    bool ok = true;
+    for (int k = 0; k <= winK && ok; k++) {
+        ok = prim_intersect_plain<ST>(S, kind, index, start, d, h, c);
+        start = h.ip + d * 1e-6;
+    }
+    if (ST & 1) { const unsigned env = c.envelope; c = keep; c.envelope = env; }
+    if (!ok) { fallback = true; return false; }          // unreachable: pass 0 found this intersection
+    h.dist = winDist;
+    h.leafKind = kind; h.leafIndex = index;
+    win = h;
+    return true;
+}
+
 // Geometry part of Node::intersect for node N on the local ray; on a hit returns the local
 // intersection point and fills t / tri / l2 / l3.
 struct LeafOut { int kind, index; };     // Cube / CSG nodes only: the plain geometry at the bottom of the tree that produced the hit
@@ -715,8 +819,17 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, L
             if (X.csgBox && ray_surely_misses_box(X.cc[0], X.cc[1], X.cc[2], X.ch[0], X.ch[1], X.ch[2], X.cM, ls.x, ls.y, ls.z, ld.x, ld.y, ld.z)) return false;
         }
         GHit h;
-        bool env = false;
-        if (!csg_intersect<ST>(S, N.geomIndex, ls, ld, ray_rdir(ld), h, env, c)) return false;
+        bool env = false, viaMachine = true, found = false;
+        const FRAY_RO DCsg& G0 = S.csgs[N.geomIndex];
+        if (G0.flat) {
+            const Cnt before = c;
+            bool fb;
+            found = csg_flat_intersect<ST>(S, G0, ls, ld, h, fb, c);
+            viaMachine = fb;                                   // (a chain of more than four intersections: the general machine answers ...
+            if ((ST & 1) && fb) { const unsigned e0 = c.envelope; c = before; c.envelope = e0; }       // ... and counts the same calls again)
+        }
+        if (viaMachine) found = csg_intersect<ST>(S, N.geomIndex, ls, ld, ray_rdir(ld), h, env, c);
+        if (!found) return false;
         if (env) c.envelope = 1;
         ipl = h.ip;
         tri = h.code;

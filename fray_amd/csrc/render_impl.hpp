@@ -276,28 +276,40 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             // The Cube / CSG kernel variants keep their hit lists in scratch memory (17 KB per lane at sixteen CsgOp levels): every stream that runs
             // one needs its own scratch arena, and three streams asking for theirs at once aborted inside the runtime (tests/test_fuzz_parity.py,
             // seed 5).  Those scenes run their batches one after the other.
-            if (ST & 2) {
-                maxLanes = std::max(1, std::min(maxLanes, sc->csgLanes));
-                // Round 5: the streams get their scratch arenas ONE AFTER THE OTHER before any batch runs -- an empty launch of each of the two kernels on
-                // every lane's stream, each waited for -- so that no two streams ask the runtime for an arena at the same moment.
-                if (maxLanes > 1 && !sc->csgWarm) {
-                    HIP_TRY(hipMemsetAsync(sc->d_qmeta, 0, 3 * FRAY_PT_LANES * sizeof(QMeta), stream));
-                    HIP_TRY(hipStreamSynchronize(stream));
-                    for (int k = 0; k < maxLanes; k++) {
-                        hipStream_t ws = k == 0 ? stream : sc->laneStream[k];
-                        QMeta* m = sc->d_qmeta + 3 * k;
-                        const QMetaRO mIn{(const FRAY_RO QMeta*)m};
-                        BounceArgs BA{};
-                        BA.S = S; BA.metaIn = mIn; BA.metaOut = m + 1; BA.metaShadow = m + 2; BA.st = sc->d_stats;
+            if (ST & 2) maxLanes = std::max(1, std::min(maxLanes, sc->csgLanes));
+            // Round 5: kernels that keep spilled registers in scratch memory must not share the chip with kernels of ANOTHER scratch size launched from other
+            // streams.  The counting variants showed it: their first bounce (76 B of scratch per lane) and their later bounces (112 B) on three batch lanes at once
+            // rendered wrong pixels in one frame in ten -- right on one lane, right when built without spills (tools/dbg_fuzz_seed.py, profiles/r05_experiments
+            // README H) -- while the timed variants of the same scenes, whose first bounce and shadow kernels use no scratch at all, never did.  So: (1) the
+            // counting variants, which are instrumentation, run their batches on ONE lane; (2) every lane's stream is primed once per scene and kernel set
+            // with an empty launch of each kernel of the set, one stream after the other, so that no queue has to enlarge its scratch arena while another
+            // lane's waves are resident.
+            if (ST & 1) maxLanes = 1;
+            const bool longRngW = 8 + 10 * (set.maxTraceDepth + 2) > 227;
+            const unsigned warmKey = 1u << ((longRngW ? 1 : 0) | (sc->fpContract ? 2 : 0) | (sc->camera.stereoSeparation > 0 ? 4 : 0));
+            if (maxLanes > 1 && !(sc->warmMask & warmKey)) {
+                HIP_TRY(hipMemsetAsync(sc->d_qmeta, 0, 3 * FRAY_PT_LANES * sizeof(QMeta), stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                for (int k = 0; k < maxLanes; k++) {
+                    hipStream_t ws = k == 0 ? stream : sc->laneStream[k];
+                    QMeta* m = sc->d_qmeta + 3 * k;
+                    const QMetaRO mIn{(const FRAY_RO QMeta*)m};
+                    BounceArgs BA{};
+                    BA.S = S; BA.metaIn = mIn; BA.metaOut = m + 1; BA.metaShadow = m + 2; BA.st = sc->d_stats;
+                    ShadowArgs SA{};
+                    SA.S = S; SA.meta = mIn; SA.st = sc->d_stats + 1;
+                    if (longRngW) hipLaunchKernelGGL((k_pt_bounce<ST, true>), dim3(1), dim3(256), 0, ws, BA);
+                    else {
                         hipLaunchKernelGGL((k_pt_bounce<ST, false>), dim3(1), dim3(256), 0, ws, BA);
                         hipLaunchKernelGGL((k_pt_bounce<ST, false, true>), dim3(1), dim3(256), 0, ws, BA);
-                        ShadowArgs SA{};
-                        SA.S = S; SA.meta = mIn; SA.st = sc->d_stats + 1;
-                        hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(1), dim3(256), 0, ws, SA);
-                        HIP_TRY(hipStreamSynchronize(ws));
                     }
-                    sc->csgWarm = true;
+                    hipLaunchKernelGGL(k_pt_shadow<ST>, dim3(1), dim3(256), 0, ws, SA);
+                    if constexpr (!(ST & 2)) {
+                        if (sc->fpContract) { launch_bounce_contracted<ST>(1, ws, BA); launch_shadow_contracted<ST>(1, ws, SA); }
+                    }
+                    HIP_TRY(hipStreamSynchronize(ws));
                 }
+                sc->warmMask |= warmKey;
             }
             // a small frame (an eighth of 1080p x 64 spp, i.e. one rank's share of an 8-rank run) is cut into fewer, larger batches:
             // measured 15.5 ms on three lanes against 15.9 on four; from a quarter of that frame upwards four lanes win

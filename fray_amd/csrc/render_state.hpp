@@ -53,7 +53,7 @@ struct frayhip_scene {
     int lastWhittedPath = 0;          // the last Whitted frame: 0 = k_whitted (recursive shaders), 1 = shade / visible / gather launches, 2 = the fused k_wh_shade (get_option "whitted_path")
     int fusedWhittedMax = 4;          // scenes whose lights take at most this many samples per hit render Whitted frames with the one-kernel path (k_whitted) instead of shade / visible / gather launches (FRAYHIP_FUSED_WHITTED_MAX)
     int csgLanes = 1;                 // batches in flight for the Cube / CSG kernel variants (FRAYHIP_CSG_LANES; their scratch arenas are made one stream at a time, render_impl)
-    bool csgWarm = false;
+    unsigned warmMask = 0;            // kernel sets whose scratch arenas the lanes' streams already hold (render_impl: empty launches, one stream after the other)
     bool fpContract = false;          // option "fp_contract": path tracing past a sample's first closest hit on the kernels built with fused multiply-adds (render_contract.hip)
     long long lastContracted = 0;     // the last frame's launches of contracted kernels (frayhip_scene_get_option "contracted_launches")
     long long lastFans[4] = {0, 0, 0, 0};   // the last frame's fans filed, children traced ahead, children looked up, fans given up part of the way (frayhip_scene_get_option)

@@ -895,10 +895,8 @@ FD bool node_intersect(const DScene& S, int i, V3 o, V3 d, LocalRay& lr, double&
             // (relaxed arithmetic: the directions the path tracer makes are unit vectors to an ulp: no second normalisation, no zero check)
             if (N.xfIdentity) { lr.s = o; lr.d = d; done = true; }
 #else
-            if (N.xfIdentity) {                     // (wave-uniform: a transformed node pays nothing for the test below)
-                const bool zeros = o.x == 0 || o.y == 0 || o.z == 0 || d.x == 0 || d.y == 0 || d.z == 0;
-                if (!__any(zeros)) { lr.s = o; lr.d = normalized(d); done = true; }
-            }
+            const bool zeros = o.x == 0 || o.y == 0 || o.z == 0 || d.x == 0 || d.y == 0 || d.z == 0;
+            if (N.xfIdentity && !__any(zeros)) { lr.s = o; lr.d = normalized(d); done = true; }
 #endif
         }
         if (!done) {
@@ -966,11 +964,10 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitT<ST>& best, Cnt& c, bool ga
     LocalRay lr;
     lr.cls = -1;
     lr.haveRd = false;
-    const bool anyGateFree = !(ST & 1) && __any(gateFree);           // wave-uniform: without such a lane the nodes' `gated` words are not even read
     for (int i = 0; i < nn; i++) {
         double dist, t, l2 = 0, l3 = 0;
         int tri = -1;
-        if (anyGateFree && gateFree && S.nodes[i].gated) continue;
+        if constexpr (!(ST & 1)) { if (gateFree && S.nodes[i].gated) continue; }
         if constexpr ((ST & 2) != 0) {
             // Cube / CSG variants: the winning intersection as its geometry reported it travels with the hit record (finalize_hit)
             V3 ipl;
@@ -1014,12 +1011,11 @@ FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c, bool gateFree = false)
     LocalRay lr;
     lr.cls = -1;
     lr.haveRd = false;
-    const bool anyGateFree = !(ST & 1) && __any(gateFree);
     for (int i = 0; i < nn; i++) {
         double dist, t, l2, l3;
         int tri;
         LeafOut lo;
-        if (anyGateFree && gateFree && S.nodes[i].gated) continue;
+        if constexpr (!(ST & 1)) { if (gateFree && S.nodes[i].gated) continue; }
         if (node_intersect<ST>(S, i, a, d, lr, dist, t, tri, l2, l3, nullptr, (ST & 2) ? &lo : nullptr, c) && dist < maxDist) return false;
     }
     return true;

@@ -38,7 +38,10 @@
                                 // bokeh.fray (k_whitted<2>, at 3 either way) 66.3 / 67.5 / 69.9 ms (profiles/r04_experiments/README.md D)
 #endif
 // waves per SIMD a kernel is register-allocated for: `n` for the common variants, FRAY_CSG_WAVES for the Cube / CSG ones
-constexpr int waves_for(int st, int n) { return (st & 2) ? (FRAY_CSG_WAVES < n ? FRAY_CSG_WAVES : n) : n; }
+// The COUNTING variants (flag bit 0: instrumentation, never timed) get one wave per SIMD less than their twins: their ten 64-bit counters per lane then
+// fit in registers instead of scratch memory.  Round 5 met the path tracer's counting kernels rendering wrong pictures -- at full frame size even faulting --
+// exactly when they kept spilled registers in scratch (profiles/r05_experiments/README.md H); spill-free they are right.
+constexpr int waves_for(int st, int n) { return (st & 2) ? (FRAY_CSG_WAVES < n ? FRAY_CSG_WAVES : n) : ((st & 1) && n > 2 ? n - 1 : n); }
 #ifndef FRAY_MT_EARLY
 #define FRAY_MT_EARLY 160       // words drawn by one lane of a k_whitted wave at which the whole wave materialises its generator states
 #endif

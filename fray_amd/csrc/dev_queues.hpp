@@ -22,15 +22,15 @@ struct PathQueue {
     unsigned char* cls;                   // the ray's class (kernels.hpp ray_sort_class): all the coherence sort reads of an entry
 };
 
-// Shadow (next-event) queue: segment a->b, the radiance to add if it is unobstructed, the sample slot: 64 bytes.
-struct alignas(16) ShadowRec {
-    double a[3], b[3];
-    float c[3];
-    uint32_t slot;
-};
+// Shadow (next-event) queue: segment a->b, the radiance to add if it is unobstructed, the sample slot.  One array per field: as 64-byte records (tried with
+// the path queue's) the shadow kernel was 4 % (cornell_box) to 12 % (smallpt, whose shadow rays cost ~600 instructions each) slower -- it reads the six
+// coordinates before the search and the rest after it, and the records' four 16-byte loads all issue up front.
 struct ShadowQueue {
-    ShadowRec* rec;
-    unsigned char* cls;
+    double* ax; double* ay; double* az;
+    double* bx; double* by; double* bz;
+    float* cr; float* cg; float* cb;
+    uint32_t* slot;
+    unsigned char* cls;                   // the segment's direction class (kernels.hpp ray_sort_class): what the shadow kernel's coherence sort reads
 };
 
 // Whitted frames of scenes whose shaders do not recurse (Lambert / Phong / Const): what Lambert::shade / Phong::shade need from

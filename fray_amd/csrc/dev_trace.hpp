@@ -967,7 +967,7 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitT<ST>& best, Cnt& c, bool ga
     for (int i = 0; i < nn; i++) {
         double dist, t, l2 = 0, l3 = 0;
         int tri = -1;
-        if constexpr (!(ST & 1)) { if (gateFree && S.nodes[i].gated) continue; }
+        if constexpr (!(ST & 1)) { if (S.nodes[i].gated) { if (gateFree) continue; } }        // (the node's word first: wave-uniform, a scalar branch for every node that is not gated)
         if constexpr ((ST & 2) != 0) {
             // Cube / CSG variants: the winning intersection as its geometry reported it travels with the hit record (finalize_hit)
             V3 ipl;
@@ -998,7 +998,9 @@ FD void closest_hit(const DScene& S, V3 o, V3 d, HitT<ST>& best, Cnt& c, bool ga
 
 // visible(a, b), main.cpp:64-80: lights do not occlude; the first node whose (full) intersection
 // lies closer than b ends the loop.
-template <int ST>
+// GATES: compiled with the test for gate-free rays (the shadow kernel takes this copy only for queues whose producer certified them: for a scene without
+// exact gates the per-node test -- a divergent branch on a lane flag -- cost its shadow kernel 9 %: smallpt, 1.30 -> 1.43 ms per launch).
+template <int ST, bool GATES = false>
 FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c, bool gateFree = false)
 {
     bump<ST>(c.shadow);
@@ -1015,7 +1017,7 @@ FD bool visible(const DScene& S, V3 a, V3 b, Cnt& c, bool gateFree = false)
         double dist, t, l2, l3;
         int tri;
         LeafOut lo;
-        if constexpr (!(ST & 1)) { if (gateFree && S.nodes[i].gated) continue; }
+        if constexpr (GATES && !(ST & 1)) { if (S.nodes[i].gated) { if (gateFree) continue; } }
         if (node_intersect<ST>(S, i, a, d, lr, dist, t, tri, l2, l3, nullptr, (ST & 2) ? &lo : nullptr, c) && dist < maxDist) return false;
     }
     return true;

@@ -1157,11 +1157,10 @@ FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitT<ST>& h, const 
             if (shadow) {
                 shadowBack = ray_gate_class(S, sa, sb - sa);
                 const uint32_t j = seg_take(shadowEnds, shadowBack);
-                ShadowRec* r = SQ.rec + j;
-                r->a[0] = sa.x; r->a[1] = sa.y; r->a[2] = sa.z;
-                r->b[0] = sb.x; r->b[1] = sb.y; r->b[2] = sb.z;
-                r->c[0] = sc.r; r->c[1] = sc.g; r->c[2] = sc.b;
-                r->slot = ps.slot;
+                SQ.ax[j] = sa.x; SQ.ay[j] = sa.y; SQ.az[j] = sa.z;
+                SQ.bx[j] = sb.x; SQ.by[j] = sb.y; SQ.bz[j] = sb.z;
+                SQ.cr[j] = sc.r; SQ.cg[j] = sc.g; SQ.cb[j] = sc.b;
+                SQ.slot[j] = ps.slot;
                 if constexpr (FRAY_SORT && sort_variant(ST)) SQ.cls[j] = (unsigned char)ray_sort_class(sb - sa, shadowBack);
             }
         }
@@ -1384,18 +1383,17 @@ static __global__ __launch_bounds__(256, anyhit_waves(ST)) void k_pt_shadow(Shad
         const bool gateFree = certFront && (i & FRAY_FRONT_BIT);
         i &= ~FRAY_FRONT_BIT;
         if (live) {
-            const ShadowRec* const r = SQ.rec + i;
-            const V3 a = v3(r->a[0], r->a[1], r->a[2]), b = v3(r->b[0], r->b[1], r->b[2]);
+            const V3 a = v3(SQ.ax[i], SQ.ay[i], SQ.az[i]), b = v3(SQ.bx[i], SQ.by[i], SQ.bz[i]);
             STAMP(0);
-            const bool vis = visible<ST>(S, a, b, c, gateFree);
-            const uint32_t sl = r->slot;
+            const bool vis = certFront ? visible<ST, true>(S, a, b, c, gateFree) : visible<ST, false>(S, a, b, c);       // (wave-uniform choice)
+            const uint32_t sl = SQ.slot[i];
 #ifdef FRAY_QCHECK
             // diagnostic build: an entry whose slot is not a slot of this batch was never written by the bounce kernel (or was consumed before): count it
             // (the frame then fails with E_UNSUPPORTED), do not store; consumed entries are poisoned
             if (sl >= TB.nPaths) { atomicAdd(&st->rngOverflow, 1ull); continue; }
-            SQ.rec[i].slot = 0xffffffffu;
+            SQ.slot[i] = 0xffffffffu;
 #endif
-            term_store(TB, sl, vis ? c3(r->c[0], r->c[1], r->c[2]) : c3(0, 0, 0));
+            term_store(TB, sl, vis ? c3(SQ.cr[i], SQ.cg[i], SQ.cb[i]) : c3(0, 0, 0));
         }
         STAMP(13);
     }

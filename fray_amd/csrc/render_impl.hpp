@@ -30,14 +30,17 @@ size_t queue_bytes(size_t n)
 unsigned char* carve_shadow(unsigned char* p, size_t n, ShadowQueue& Q)
 {
     auto take = [&](size_t bytes) { unsigned char* r = p; p += (bytes + 255) / 256 * 256; return r; };
-    Q.rec = (ShadowRec*)take(n * sizeof(ShadowRec));
+    Q.ax = (double*)take(n * 8); Q.ay = (double*)take(n * 8); Q.az = (double*)take(n * 8);
+    Q.bx = (double*)take(n * 8); Q.by = (double*)take(n * 8); Q.bz = (double*)take(n * 8);
+    Q.cr = (float*)take(n * 4); Q.cg = (float*)take(n * 4); Q.cb = (float*)take(n * 4);
+    Q.slot = (uint32_t*)take(n * 4);
     Q.cls = take(n);
     return p;
 }
 size_t shadow_bytes(size_t n)
 {
     auto r = [](size_t b) { return (b + 255) / 256 * 256; };
-    return r(n * sizeof(ShadowRec)) + r(n);
+    return 6 * r(n * 8) + 4 * r(n * 4) + r(n);
 }
 }  // namespace
 
@@ -287,7 +290,7 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
             if (ST & 1) maxLanes = 1;
             const bool longRngW = 8 + 10 * (set.maxTraceDepth + 2) > 227;
             const unsigned warmKey = 1u << ((longRngW ? 1 : 0) | (sc->fpContract ? 2 : 0) | (sc->camera.stereoSeparation > 0 ? 4 : 0));
-            if (maxLanes > 1 && !(sc->warmMask & warmKey)) {
+            if (maxLanes > 1 && !(sc->warmMask & warmKey) && !getenv("FRAYHIP_NO_PRIME")) {
                 HIP_TRY(hipMemsetAsync(sc->d_qmeta, 0, 3 * FRAY_PT_LANES * sizeof(QMeta), stream));
                 HIP_TRY(hipStreamSynchronize(stream));
                 for (int k = 0; k < maxLanes; k++) {

@@ -27,7 +27,8 @@ __device__ bool lane_of(lanes_t m);
 // through DStats.stamp, which nothing else reads.
 #ifdef FRAY_STAMPS
 __shared__ unsigned long long g_stampT0[4];
-__shared__ unsigned long long g_stampAcc[4][16];
+__shared__ unsigned long long g_stampAcc[4][24];
+__shared__ unsigned long long g_stampLanes[4][24];     // the same cycles weighted by the lanes active at the stamp: lanes / (64 x cycles) = how full the section ran
 FD void STAMP(int k)
 {
     __builtin_amdgcn_sched_barrier(0);
@@ -35,6 +36,7 @@ FD void STAMP(int k)
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     const int w = threadIdx.x >> 6;
     g_stampAcc[w][k] += t - g_stampT0[w];
+    g_stampLanes[w][k] += (t - g_stampT0[w]) * (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
     g_stampT0[w] = t;
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -43,7 +45,7 @@ FD void stamp_begin()
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     const int w = threadIdx.x >> 6;
-    for (int k = 0; k < 16; k++) g_stampAcc[w][k] = 0;
+    for (int k = 0; k < 24; k++) { g_stampAcc[w][k] = 0; g_stampLanes[w][k] = 0; }
     g_stampT0[w] = t;
 }
 #else

@@ -209,7 +209,8 @@ struct DFrame {
 struct DStats {
     unsigned long long closest, shadow, node, kdInner, leafRefs, tri, prim, smooth, samples, tex, rngOverflow;   // rngOverflow: any "left the supported envelope" event
 #ifdef FRAY_STAMPS
-    unsigned long long stamp[16];   // diagnostic build: wave cycles per section (dev_math.hpp STAMP)
+    unsigned long long stamp[24];   // diagnostic build: wave cycles per section (dev_math.hpp STAMP)
+    unsigned long long stampLanes[24];
 #endif
 };
 // Work cursors of the persistent kernels (kernels.hpp claim_items): one per cache line.

@@ -556,9 +556,22 @@ FD bool prim_intersect(const DScene& S, int kind, int index, V3 s, V3 d, V3 rd, 
 struct CsgFrame {
     double s[3];          // the ray start this CsgOp was asked about
     double winDist;
+    double last;          // pass 0: the distance recorded last (is the current chain in non-decreasing order?)
     int32_t csg;          // index into DScene::csgs
     unsigned char n, k, cnt0, cnt1, winOp, winK, pass, op;
+    uint32_t unsorted;    // pass 0: some chain came out of order (NaNs included): the walk needs std::sort's own order
 };
+// Round 5: what pass 0 computed is KEPT for the first FRAY_CSG_MEMO intersections of the FRAY_CSG_MEMO_LEVELS outermost activations, so that the winner's
+// record is looked up instead of derived again (the reference computes every intersection once and keeps all thirty records per operand, geometry.cpp:144-152;
+// deriving the winner again was this port's way of not holding them).  In a nested tree a pass 1 re-asks whole sub-trees, each with its own two passes: for
+// csg_nested.fray's three-level objects a ray that hits asked 218 plain geometries, now 66.  Longer chains and deeper activations still take pass 1.
+#ifndef FRAY_CSG_MEMO
+#define FRAY_CSG_MEMO 8
+#endif
+#ifndef FRAY_CSG_MEMO_LEVELS
+#define FRAY_CSG_MEMO_LEVELS 4
+#endif
+struct CsgMemo { double ip[3]; double l2, l3; int32_t code, leafKind, leafIndex, pad; };
 template <int ST>
 FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win, bool& envelope, Cnt& c)
 {
@@ -567,11 +580,14 @@ FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win
     CsgFrame fr[FRAY_CSG_DEPTH];
     double dist[FRAY_CSG_DEPTH][2 * FRAY_CSG_MAX];
     unsigned char order[FRAY_CSG_DEPTH][2 * FRAY_CSG_MAX];
+#if FRAY_CSG_MEMO
+    CsgMemo memo[FRAY_CSG_MEMO_LEVELS][FRAY_CSG_MEMO];
+#endif
     int level = 0, quietAt = -1;
     V3 start = s;
     CsgFrame F;
     F.s[0] = s.x; F.s[1] = s.y; F.s[2] = s.z;
-    F.winDist = 0;
+    F.winDist = 0; F.last = 0; F.unsorted = 0;
     F.csg = rootCsg; F.n = F.k = F.cnt0 = F.cnt1 = F.winOp = F.winK = F.pass = F.op = 0;
     for (;;) {
         // ---- ASK
@@ -586,7 +602,7 @@ FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win
                     fr[level] = F;
                     level++;
                     F.s[0] = start.x; F.s[1] = start.y; F.s[2] = start.z;
-                    F.winDist = 0;
+                    F.winDist = 0; F.last = 0; F.unsorted = 0;
                     F.csg = index; F.n = F.k = F.cnt0 = F.cnt1 = F.winOp = F.winK = F.pass = F.op = 0;
                     continue;
                 }
@@ -598,7 +614,9 @@ FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win
                     ok = prim_intersect<ST>(S, kind, index, start, d, rd, h, c);
                     if (quietAt >= 0) { const unsigned env = c.envelope; c = keep; c.envelope = env; }
                 } else {
+                    STAMP(20);
                     ok = prim_intersect<ST>(S, kind, index, start, d, rd, h, c);
+                    if (kind != 3) STAMP(18);
                 }
                 h.leafKind = kind; h.leafIndex = index;
             }
@@ -610,8 +628,19 @@ FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win
             if (ok && F.pass == 0 && F.k == FRAY_CSG_MAX) ok = false;          // `counter-- > 0`: the 31st intersection is found and dropped
             if (ok) {
                 if (F.pass == 0) {
-                    dist[level][F.n] = F.k > 0 ? length(h.ip - fs) : h.dist;   // geometry.cpp:155-156
-                    order[level][F.n] = F.n;
+                    const double dv = F.k > 0 ? length(h.ip - fs) : h.dist;    // geometry.cpp:155-156
+                    if (F.k > 0 && !(dv >= F.last)) F.unsorted = 1;
+                    if (!(dv == dv)) F.unsorted = 1;
+                    F.last = dv;
+                    dist[level][F.n] = dv;
+#if FRAY_CSG_MEMO
+                    if (level < FRAY_CSG_MEMO_LEVELS && F.n < FRAY_CSG_MEMO) {
+                        CsgMemo& M = memo[level][F.n];
+                        M.ip[0] = h.ip.x; M.ip[1] = h.ip.y; M.ip[2] = h.ip.z;
+                        M.l2 = h.l2; M.l3 = h.l3;
+                        M.code = h.code; M.leafKind = h.leafKind; M.leafIndex = h.leafIndex;
+                    }
+#endif
                     F.n++; F.k++;
                     start = h.ip + d * 1e-6;
                 } else if (F.k == F.winK) {
@@ -627,30 +656,62 @@ FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win
                     F.cnt1 = F.k;
                     const FRAY_RO DCsg& G = S.csgs[F.csg];
                     const int n = F.n, c0 = F.cnt0;
-                    StdSort sorter{dist[level], order[level]};
-                    sorter.sort(n);
                     bool inL = (c0 & 1) == 1, inR = (F.cnt1 & 1) == 1;
                     auto bop = [&](bool l, bool r) { return G.op == 0 ? (l || r) : (G.op == 1 ? (l && r) : (l && !r)); };
                     const bool cur = bop(inL, inR);
-                    bool any = false;
-                    for (int i = 0; i < n && !any; i++) {
-                        const int e = order[level][i], o = e < c0 ? 0 : 1;
-                        if (o == 0) inL = !inL; else inR = !inR;
-                        if (bop(inL, inR) != cur) { any = true; F.winOp = (unsigned char)o; F.winK = (unsigned char)(o == 0 ? e : e - c0); F.winDist = dist[level][e]; }
+                    int winE = -1;                                // the winner: entry e of dist[level] (e < c0: the left operand's e-th, else the right one's)
+                    if (!F.unsorted && n <= 16) {
+                        // Both chains in non-decreasing order and at most sixteen entries: libstdc++'s std::sort is then its final insertion sort alone (strict
+                        // comparisons: equal elements keep their order), i.e. the stable merge of the two chains with the left operand's entry first among
+                        // equals -- walked here without sorting anything.
+                        int i = 0, j = c0;
+                        double dl = i < c0 ? dist[level][i] : 0.0, dr = j < n ? dist[level][j] : 0.0;
+                        while (winE < 0 && (i < c0 || j < n)) {
+                            const bool takeL = j >= n || (i < c0 && !(dr < dl));
+                            if (takeL) inL = !inL; else inR = !inR;
+                            if (bop(inL, inR) != cur) winE = takeL ? i : j;
+                            else if (takeL) { i++; if (i < c0) dl = dist[level][i]; }
+                            else { j++; if (j < n) dr = dist[level][j]; }
+                        }
+                    } else {
+                        for (int i = 0; i < n; i++) order[level][i] = (unsigned char)i;
+                        StdSort sorter{dist[level], order[level]};
+                        sorter.sort(n);
+                        for (int i = 0; i < n && winE < 0; i++) {
+                            const int e = order[level][i];
+                            if (e < c0) inL = !inL; else inR = !inR;
+                            if (bop(inL, inR) != cur) winE = e;
+                        }
                     }
-                    if (!any) answer = true;                      // (false, -)
+                    if (winE < 0) answer = true;                  // (false, -)
                     else {
-                        F.pass = 1; F.op = F.winOp; F.k = 0; start = fs;
-                        if (quietAt < 0) quietAt = level;
+                        const int o = winE < c0 ? 0 : 1;
+                        F.winOp = (unsigned char)o; F.winK = (unsigned char)(o == 0 ? winE : winE - c0); F.winDist = dist[level][winE];
+#if FRAY_CSG_MEMO
+                        if (level < FRAY_CSG_MEMO_LEVELS && winE < FRAY_CSG_MEMO) {
+                            const CsgMemo& M = memo[level][winE];
+                            h.ip = v3(M.ip[0], M.ip[1], M.ip[2]);
+                            h.l2 = M.l2; h.l3 = M.l3;
+                            h.code = M.code; h.leafKind = M.leafKind; h.leafIndex = M.leafIndex;
+                            h.dist = F.winDist;
+                            ok = true;
+                            answer = true;
+                        } else
+#endif
+                        {
+                            F.pass = 1; F.op = F.winOp; F.k = 0; start = fs;
+                            if (quietAt < 0) quietAt = level;
+                        }
                     }
                 }
             } else answer = true;                                 // unreachable: pass 0 found this intersection
             if (!answer) break;
             if (quietAt == level) quietAt = -1;
-            if (level == 0) { win = h; return ok; }
+            if (level == 0) { win = h; STAMP(19); return ok; }
             level--;
             F = fr[level];
         }
+        STAMP(19);
     }
 }
 
@@ -816,7 +877,9 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, L
             // CERTIFIABLY passes the tree's bounding box by (dev_misscert.hpp: then no operand reports an intersection, as the reference computes
             // them) gets the reference's answer -- none -- without the machine.  (The counting variants run it: their counters are the reference's calls.)
             const FRAY_RO DNodeX& X = S.nodesX[nodeIndex];
-            if (X.csgBox && ray_surely_misses_box(X.cc[0], X.cc[1], X.cc[2], X.ch[0], X.ch[1], X.ch[2], X.cM, ls.x, ls.y, ls.z, ld.x, ld.y, ld.z)) return false;
+            const bool passesBy = X.csgBox && ray_surely_misses_box(X.cc[0], X.cc[1], X.cc[2], X.ch[0], X.ch[1], X.ch[2], X.cM, ls.x, ls.y, ls.z, ld.x, ld.y, ld.z);
+            STAMP(16);
+            if (passesBy) return false;
         }
         GHit h;
         bool env = false, viaMachine = true, found = false;
@@ -827,8 +890,9 @@ FD bool geom_intersect(const DScene& S, const FRAY_RO DNode& N, int nodeIndex, L
             found = csg_flat_intersect<ST>(S, G0, ls, ld, h, fb, c);
             viaMachine = fb;                                   // (a chain of more than four intersections: the general machine answers ...
             if ((ST & 1) && fb) { const unsigned e0 = c.envelope; c = before; c.envelope = e0; }       // ... and counts the same calls again)
+            STAMP(17);
         }
-        if (viaMachine) found = csg_intersect<ST>(S, N.geomIndex, ls, ld, ray_rdir(ld), h, env, c);
+        if (viaMachine) { found = csg_intersect<ST>(S, N.geomIndex, ls, ld, ray_rdir(ld), h, env, c); STAMP(20); }
         if (!found) return false;
         if (env) c.envelope = 1;
         ipl = h.ip;

@@ -257,7 +257,7 @@ static __global__ __launch_bounds__(256, primary_waves(ST)) void k_primary(Prima
         STAMP(13);
     }
 #ifdef FRAY_STAMPS
-    if ((threadIdx.x & 63) < 16) atomicAdd(&A.st->stamp[threadIdx.x & 63], g_stampAcc[threadIdx.x >> 6][threadIdx.x & 63]);
+    if ((threadIdx.x & 63) < 24) { atomicAdd(&A.st->stamp[threadIdx.x & 63], g_stampAcc[threadIdx.x >> 6][threadIdx.x & 63]); atomicAdd(&A.st->stampLanes[threadIdx.x & 63], g_stampLanes[threadIdx.x >> 6][threadIdx.x & 63]); }
 #endif
     if (ST & 1) flush_stats(A.st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&A.st->rngOverflow, 1ull);
@@ -535,7 +535,7 @@ static __global__ __launch_bounds__(256, whitted_waves(ST, MODE)) void k_whitted
         STAMP(10);
     }
 #ifdef FRAY_STAMPS
-    if (lane < 16) atomicAdd(&st->stamp[lane], g_stampAcc[threadIdx.x >> 6][lane]);
+    if (lane < 24) { atomicAdd(&st->stamp[lane], g_stampAcc[threadIdx.x >> 6][lane]); atomicAdd(&st->stampLanes[lane], g_stampLanes[threadIdx.x >> 6][lane]); }
 #endif
     if (MODE == 3) {                                                        // how the speculation went (frayhip_scene_get_option)
         int a = SL.looked, b = SL.missed;
@@ -714,7 +714,7 @@ static __global__ __launch_bounds__(256, waves_for(ST, FRAY_WH_SHADE_WAVES)) voi
         }
     }
 #ifdef FRAY_STAMPS
-    if ((threadIdx.x & 63) < 16) atomicAdd(&st->stamp[threadIdx.x & 63], g_stampAcc[threadIdx.x >> 6][threadIdx.x & 63]);
+    if ((threadIdx.x & 63) < 24) { atomicAdd(&st->stamp[threadIdx.x & 63], g_stampAcc[threadIdx.x >> 6][threadIdx.x & 63]); atomicAdd(&st->stampLanes[threadIdx.x & 63], g_stampLanes[threadIdx.x >> 6][threadIdx.x & 63]); }
 #endif
     if (ovf) atomicAdd(&st->rngOverflow, 1ull);
     if (ST & 1) flush_stats(st, c);
@@ -748,7 +748,7 @@ static __global__ __launch_bounds__(256, anyhit_waves(ST)) void k_wh_visible(WhV
         Q.vis[t] = visible<ST>(S, v3(Q.ax[e], Q.ay[e], Q.az[e]), v3(Q.bx[t], Q.by[t], Q.bz[t]), c) ? 1 : 0;
     }
 #ifdef FRAY_STAMPS
-    if ((threadIdx.x & 63) < 16) atomicAdd(&st->stamp[threadIdx.x & 63], g_stampAcc[threadIdx.x >> 6][threadIdx.x & 63]);
+    if ((threadIdx.x & 63) < 24) { atomicAdd(&st->stamp[threadIdx.x & 63], g_stampAcc[threadIdx.x >> 6][threadIdx.x & 63]); atomicAdd(&st->stampLanes[threadIdx.x & 63], g_stampLanes[threadIdx.x >> 6][threadIdx.x & 63]); }
 #endif
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);
@@ -795,9 +795,13 @@ FD const Mt& cursor(const MtPath& g) { return g.r; }
 
 // Direction class of a ray for the consumers' coherence sort (sort_share below): the octant of its direction in Gray-code order (neighbouring
 // classes differ in ONE sign), and, as the high bit, whether it may enter one of the scene's gates (ray_gate_class).  A scheduling key, nothing else.
-FD uint32_t ray_sort_class(V3 d, bool gate)
+// Cube / CSG variants (ST & 2): what costs there is a CsgOp node's machine, which only the lanes that enter that node's box run -- so a ray that may enter a gate
+// is classed by WHICH gate (`gate` = 1 + the first gate it may enter, 0 = none): the few rays of a share that run the same machine then sit in the same wave.
+template <int ST>
+FD uint32_t ray_sort_class(V3 d, uint32_t gate)
 {
     const uint32_t g = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
+    if constexpr ((ST & 2) != 0) { if (gate) return 8u + (gate - 1u < 6u ? gate - 1u : 6u); }
     return (g ^ (g >> 1) ^ (g >> 2)) | (gate ? 8u : 0u);
 }
 // STORE_CLS: only the variants whose consumers sort (sort_variant) read the class array
@@ -927,7 +931,10 @@ FD uint32_t seg_map(const FRAY_RO uint32_t* off, const FRAY_RO uint32_t* nf, uin
 // (Lambert / mirror / glass / other) instead of its direction -- north_star's sort-by-material, as far as a queue between bounces can know a material.
 constexpr bool sort_variant(int) { return true; }
 #else
-constexpr bool sort_variant(int st) { return (st & 6) == 4; }
+#ifndef FRAY_SORT_CSG
+#define FRAY_SORT_CSG 0
+#endif
+constexpr bool sort_variant(int st) { return (st & 6) == 4 || (FRAY_SORT_CSG && (st & 2) != 0); }
 #endif
 FD void wave_lds_sync()
 {
@@ -1035,7 +1042,7 @@ static __global__ __launch_bounds__(256) void k_pt_init(DScene S, DCamera C, DFr
             ps.depth = 0;
             ps.flags = 0;
             bump<ST>(c.samples);
-            path_store<FRAY_SORT && sort_variant(ST)>(Q, slot, ps, ray_sort_class(ps.d, false));
+            path_store<FRAY_SORT && sort_variant(ST)>(Q, slot, ps, ray_sort_class<ST>(ps.d, 0u));
         } else {
             // no path in this slot: a zero direction says so to the bounce kernel (which then needs no load beyond the ray's own 48 bytes to know)
             PathRec* r = Q.rec + slot;
@@ -1068,33 +1075,34 @@ FD WaveShare wave_share(uint32_t n)
 // of the meshes with long brute-force triangle loops).  A slab test in FP32 on the world-space box -- a scheduling hint, nothing else.
 // Round 5: when every gate of the scene is EXACT (DGate::exact: untransformed nodes) the test is dev_misscert.hpp's FP32 certificate instead, "gate-free" is
 // then proven, and the consumers skip the gated nodes for the rays filed at the front (closest_hit / visible, `gateFree`).
-FD bool ray_gate_class(const DScene& S, V3 o, V3 d)
+// Returns 0 for a gate-free ray, else 1 + the index of the first gate it may enter.
+FD uint32_t ray_gate_class(const DScene& S, V3 o, V3 d)
 {
     const int ng = S.nGates;
-    if (ng == 0) return false;
+    if (ng == 0) return 0u;
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
     if (S.gatesExact) {
         const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
         const float omax = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)), dsum = fabsf(dx) + fabsf(dy) + fabsf(dz);
-        bool any = false;
-        for (int g = 0; g < ng; g++) {
+        uint32_t first = 0;
+        for (int g = ng - 1; g >= 0; g--) {
             const FRAY_RO DGate& G = S.gates[g];
-            any = any || !ray_surely_misses_box_f32(G.cf[0], G.cf[1], G.cf[2], G.hf[0], G.hf[1], G.hf[2], G.Mf, ox, oy, oz, dx, dy, dz, omax, dsum);
+            if (!ray_surely_misses_box_f32(G.cf[0], G.cf[1], G.cf[2], G.hf[0], G.hf[1], G.hf[2], G.Mf, ox, oy, oz, dx, dy, dz, omax, dsum)) first = (uint32_t)g + 1u;
         }
-        return any || !(omax < 1e9f);
+        return !(omax < 1e9f) && !first ? 1u : first;
     }
     const float rx = __builtin_amdgcn_rcpf((float)d.x), ry = __builtin_amdgcn_rcpf((float)d.y), rz = __builtin_amdgcn_rcpf((float)d.z);
-    bool any = false;
-    for (int g = 0; g < ng; g++) {
+    uint32_t first = 0;
+    for (int g = ng - 1; g >= 0; g--) {
         const FRAY_RO DGate& G = S.gates[g];
         const float ax = ((float)G.lo[0] - ox) * rx, bx = ((float)G.hi[0] - ox) * rx;
         const float ay = ((float)G.lo[1] - oy) * ry, by = ((float)G.hi[1] - oy) * ry;
         const float az = ((float)G.lo[2] - oz) * rz, bz = ((float)G.hi[2] - oz) * rz;
         const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
         const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-        any = any || !(t0 > t1 * 1.0001f + 1e-3f);          // NaNs (a direction component of 0 on a box face) count as "may enter"
+        if (!(t0 > t1 * 1.0001f + 1e-3f)) first = (uint32_t)g + 1u;          // NaNs (a direction component of 0 on a box face) count as "may enter"
     }
-    return any;
+    return first;
 }
 
 // Where the lanes of one batch of 64 append to a wave's queue segment: the gate-free rays at the front (in order), the others at the back (in
@@ -1131,7 +1139,7 @@ FD void seg_advance(SegEnds& E, bool put, bool back)
 // segment sa -> sb carrying sc), the real spawnRay, the throughput update and the entry test of the next iteration
 // (`cont`: ps is the path to continue).
 template <int ST, bool BARY, class G>
-FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitT<ST>& h, const TermBuf& TB, DStats* st, const StereoBuf& SB, bool& cont, bool& shadow, bool& shadowBack,
+FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitT<ST>& h, const TermBuf& TB, DStats* st, const StereoBuf& SB, bool& cont, bool& shadow, uint32_t& shadowBack,
                    const ShadowQueue& SQ, const SegEndsShared& shadowEnds, Cnt& c)
 {
     C3 own = c3(0, 0, 0);          // this bounce's term, unless a queued next-event segment will provide it
@@ -1156,12 +1164,12 @@ FD void path_shade(const DScene& S, PathStateT<G>& ps, const HitT<ST>& h, const 
             shadow = nee_prepare(S, ps.d, info, ps.pm, sh, ps.rnd, ps.tab, sa, sb, sc);
             if (shadow) {
                 shadowBack = ray_gate_class(S, sa, sb - sa);
-                const uint32_t j = seg_take(shadowEnds, shadowBack);
+                const uint32_t j = seg_take(shadowEnds, shadowBack != 0);
                 SQ.ax[j] = sa.x; SQ.ay[j] = sa.y; SQ.az[j] = sa.z;
                 SQ.bx[j] = sb.x; SQ.by[j] = sb.y; SQ.bz[j] = sb.z;
                 SQ.cr[j] = sc.r; SQ.cg[j] = sc.g; SQ.cb[j] = sc.b;
                 SQ.slot[j] = ps.slot;
-                if constexpr (FRAY_SORT && sort_variant(ST)) SQ.cls[j] = (unsigned char)ray_sort_class(sb - sa, shadowBack);
+                if constexpr (FRAY_SORT && sort_variant(ST)) SQ.cls[j] = (unsigned char)ray_sort_class<ST>(sb - sa, shadowBack);
             }
         }
         PathRay win, wout;
@@ -1248,7 +1256,8 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
         const StereoBuf& SB = KARG(BounceArgs, AP, SB);
         const LongRng& LR = KARG(BounceArgs, AP, LR);
         const uint32_t di = base + lane;
-        bool cont = false, shadow = false, shadowBack = false, gateFree = false;
+        bool cont = false, shadow = false, gateFree = false;
+        uint32_t shadowBack = 0;
         PathStateT<G> ps;
         bool live = di < b1;
         uint32_t i = di, seed0 = 0;
@@ -1312,19 +1321,20 @@ static __global__ __launch_bounds__(256, waves_for(ST, kd_variant(ST) ? FRAY_BOU
         }
         // survivors and next-event segments of this batch of 64 paths go to the wave's own segments of the output queues: gate-free rays to
         // the front, the others to the back (ballot ranks, no global counter)
-        const bool back = cont && ray_gate_class(S, ps.o, ps.d);
+        const uint32_t gate = cont ? ray_gate_class(S, ps.o, ps.d) : 0u;
+        const bool back = gate != 0;
         const uint32_t slotOut = seg_slot(outEnds, cont, back);
 #ifdef FRAY_SORT_BY_MATERIAL
         if (cont) path_store<true>(Qout, slotOut, ps, (ps.flags >> 8) & 3u);
 #else
-        if (cont) path_store<FRAY_SORT && sort_variant(ST)>(Qout, slotOut, ps, ray_sort_class(ps.d, back));
+        if (cont) path_store<FRAY_SORT && sort_variant(ST)>(Qout, slotOut, ps, ray_sort_class<ST>(ps.d, gate));
 #endif
         seg_advance(outEnds, cont, back);
         STAMP(13);
     }
     }
 #ifdef FRAY_STAMPS
-    if (lane < 16) atomicAdd(&st->stamp[lane], g_stampAcc[threadIdx.x >> 6][lane]);
+    if (lane < 24) { atomicAdd(&st->stamp[lane], g_stampAcc[threadIdx.x >> 6][lane]); atomicAdd(&st->stampLanes[lane], g_stampLanes[threadIdx.x >> 6][lane]); }
 #endif
     if (lane == 0) {
         metaOut->cnt[ws.w] = outEnds.nF + outEnds.nB; metaOut->nf[ws.w] = outEnds.nF;
@@ -1399,7 +1409,7 @@ static __global__ __launch_bounds__(256, anyhit_waves(ST)) void k_pt_shadow(Shad
     }
     }
 #ifdef FRAY_STAMPS
-    if (lane < 16) atomicAdd(&st->stamp[lane], g_stampAcc[threadIdx.x >> 6][lane]);
+    if (lane < 24) { atomicAdd(&st->stamp[lane], g_stampAcc[threadIdx.x >> 6][lane]); atomicAdd(&st->stampLanes[lane], g_stampLanes[threadIdx.x >> 6][lane]); }
 #endif
     if (ST & 1) flush_stats(st, c);
     if ((ST & 2) && c.envelope) atomicAdd(&st->rngOverflow, 1ull);

@@ -478,14 +478,15 @@ int render_impl(frayhip_scene* sc, const frayhip_frame* f, float* d_rgb, int32_t
 #endif
 #ifdef FRAY_STAMPS
     {
-        static const char* names[16] = {"queue lookup + ray load / camera ray", "local ray (transform)", "root box test", "tree-less triangle loop", "KD walk: child tests", "other geometry (plane / sphere / KD leaf accept)",
+        static const char* names[24] = {"queue lookup + ray load / camera ray", "local ray (transform)", "root box test", "tree-less triangle loop", "KD walk: child tests", "other geometry (plane / sphere / KD leaf accept)",
                                         "node result + world distance", "lights", "load rest of path", "KD walk: climbs", "shading (finalize .. spawn / light loops)", "KD leaves: FP64 tests of the candidates",
-                                        "k_whitted: cheap steps (returns, loop heads, pushes; pixel / sample set-up)", "queue stores / loop overhead", "k_whitted: rest of the trace step (attributes, bump)", "KD leaves: FP32 filter"};
+                                        "k_whitted: cheap steps (returns, loop heads, pushes; pixel / sample set-up)", "queue stores / loop overhead", "k_whitted: rest of the trace step (attributes, bump)", "KD leaves: FP32 filter",
+                                        "CsgOp: bounding-box certificate", "CsgOp over two plain operands (no machine)", "CsgOp machine: plain operand asked", "CsgOp machine: answers delivered (sort, in / out walk)", "CsgOp machine: pushes, mesh operand's remainder", "", "", ""};
         for (int q = 0; q < 2; q++) {
             double tot = 0;
-            for (int k = 0; k < 16; k++) tot += (double)dsv[q].stamp[k];
+            for (int k = 0; k < 24; k++) tot += (double)dsv[q].stamp[k];
             fprintf(stderr, "[stamps] %s: total %.4g wave-cycles\n", q == 0 ? "closest-hit kernel (k_pt_bounce / k_primary / k_wh_shade)" : "any-hit kernel (k_pt_shadow / k_wh_visible)", tot);
-            for (int k = 0; k < 16; k++) if (dsv[q].stamp[k]) fprintf(stderr, "[stamps]   %-36s %6.2f %%   (%llu)\n", names[k], 100.0 * (double)dsv[q].stamp[k] / tot, (unsigned long long)dsv[q].stamp[k]);
+            for (int k = 0; k < 24; k++) if (dsv[q].stamp[k]) fprintf(stderr, "[stamps]   %2d %-36s %6.2f %%   lanes %.3f   (%llu)\n", k, names[k], 100.0 * (double)dsv[q].stamp[k] / tot, (double)dsv[q].stampLanes[k] / (64.0 * (double)dsv[q].stamp[k]), (unsigned long long)dsv[q].stamp[k]);
         }
     }
 #endif

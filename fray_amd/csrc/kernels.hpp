@@ -931,6 +931,9 @@ FD uint32_t seg_map(const FRAY_RO uint32_t* off, const FRAY_RO uint32_t* nf, uin
 // (Lambert / mirror / glass / other) instead of its direction -- north_star's sort-by-material, as far as a queue between bounces can know a material.
 constexpr bool sort_variant(int) { return true; }
 #else
+// FRAY_SORT_CSG (off): the Cube / CSG variants sorting too, a ray's class being WHICH gate it may enter (ray_sort_class<ST>).  Measured on csg_nested.fray path
+// traced: 55.9 -> 62.0 ms, and the CsgOp machine's lane utilisation does not move (0.280 -> 0.283): its idle lanes are not lanes of another object, they are
+// the rays of the SAME object that left its machine after six steps while a ray that hits runs sixty (profiles/r05_experiments/README.md J).
 #ifndef FRAY_SORT_CSG
 #define FRAY_SORT_CSG 0
 #endif

@@ -560,7 +560,13 @@ struct CsgFrame {
     int32_t csg;          // index into DScene::csgs
     unsigned char n, k, cnt0, cnt1, winOp, winK, pass, op;
     uint32_t unsorted;    // pass 0: some chain came out of order (NaNs included): the walk needs std::sort's own order
+    int32_t leftIndex, rightIndex, kinds;     // the CsgOp itself (DCsg), read once when the activation starts: kinds = leftKind | rightKind << 8 | op << 16
 };
+FD void csg_frame_op(CsgFrame& F, const FRAY_RO DCsg& G)
+{
+    F.leftIndex = G.leftIndex; F.rightIndex = G.rightIndex;
+    F.kinds = G.leftKind | (G.rightKind << 8) | (G.op << 16);
+}
 // Round 5: what pass 0 computed is KEPT for the first FRAY_CSG_MEMO intersections of the FRAY_CSG_MEMO_LEVELS outermost activations, so that the winner's
 // record is looked up instead of derived again (the reference computes every intersection once and keeps all thirty records per operand, geometry.cpp:144-152;
 // deriving the winner again was this port's way of not holding them).  In a nested tree a pass 1 re-asks whole sub-trees, each with its own two passes: for
@@ -589,14 +595,16 @@ FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win
     F.s[0] = s.x; F.s[1] = s.y; F.s[2] = s.z;
     F.winDist = 0; F.last = 0; F.unsorted = 0;
     F.csg = rootCsg; F.n = F.k = F.cnt0 = F.cnt1 = F.winOp = F.winK = F.pass = F.op = 0;
+    csg_frame_op(F, S.csgs[rootCsg]);
     for (;;) {
         // ---- ASK
         bool ok;
         GHit h;
         {
-            const FRAY_RO DCsg& G = S.csgs[F.csg];
+            // (the operator's record travels in the activation: a load per question -- its address depends on the lane's activation -- stood in front of every
+            // operand's own load)
             const int op = F.op;
-            const int kind = op == 0 ? G.leftKind : G.rightKind, index = op == 0 ? G.leftIndex : G.rightIndex;
+            const int kind = op == 0 ? (F.kinds & 255) : ((F.kinds >> 8) & 255), index = op == 0 ? F.leftIndex : F.rightIndex;
             if (kind == 4) {
                 if (level + 1 < FRAY_CSG_DEPTH) {
                     fr[level] = F;
@@ -604,6 +612,7 @@ FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win
                     F.s[0] = start.x; F.s[1] = start.y; F.s[2] = start.z;
                     F.winDist = 0; F.last = 0; F.unsorted = 0;
                     F.csg = index; F.n = F.k = F.cnt0 = F.cnt1 = F.winOp = F.winK = F.pass = F.op = 0;
+                    csg_frame_op(F, S.csgs[index]);
                     continue;
                 }
                 envelope = true;          // unreachable: frayhip_scene_create rejects deeper trees
@@ -654,10 +663,9 @@ FD bool csg_intersect(const DScene& S, int rootCsg, V3 s, V3 d, V3 rd, GHit& win
                 if (F.op == 0) { F.cnt0 = F.k; F.op = 1; F.k = 0; start = fs; }
                 else {
                     F.cnt1 = F.k;
-                    const FRAY_RO DCsg& G = S.csgs[F.csg];
-                    const int n = F.n, c0 = F.cnt0;
+                    const int n = F.n, c0 = F.cnt0, gop = F.kinds >> 16;
                     bool inL = (c0 & 1) == 1, inR = (F.cnt1 & 1) == 1;
-                    auto bop = [&](bool l, bool r) { return G.op == 0 ? (l || r) : (G.op == 1 ? (l && r) : (l && !r)); };
+                    auto bop = [&](bool l, bool r) { return gop == 0 ? (l || r) : (gop == 1 ? (l && r) : (l && !r)); };
                     const bool cur = bop(inL, inR);
                     int winE = -1;                                // the winner: entry e of dist[level] (e < c0: the left operand's e-th, else the right one's)
                     if (!F.unsorted && n <= 16) {

@@ -932,8 +932,9 @@ FD uint32_t seg_map(const FRAY_RO uint32_t* off, const FRAY_RO uint32_t* nf, uin
 constexpr bool sort_variant(int) { return true; }
 #else
 // FRAY_SORT_CSG (off): the Cube / CSG variants sorting too, a ray's class being WHICH gate it may enter (ray_sort_class<ST>).  Measured on csg_nested.fray path
-// traced: 55.9 -> 62.0 ms, and the CsgOp machine's lane utilisation does not move (0.280 -> 0.283): its idle lanes are not lanes of another object, they are
-// the rays of the SAME object that left its machine after six steps while a ray that hits runs sixty (profiles/r05_experiments/README.md J).
+// traced: 55.9 -> 62.0 ms; the share of a wave that enters a CsgOp machine stays 0.38 (0.39 unsorted) and the lanes inside it 0.23: a wave's share of the queue holds a
+// dozen rays per object, and inside a machine a ray that hits asks sixty plain geometries where one that finds nothing asks six.  Regrouping the gate rays of all
+// producer segments first (a second dense order out of k_scan, balanced slices per wave) was built as well: bit-identical, +1.5 ... +28 % (profiles/r05_experiments/README.md J).
 #ifndef FRAY_SORT_CSG
 #define FRAY_SORT_CSG 0
 #endif

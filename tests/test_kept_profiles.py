@@ -71,3 +71,21 @@ def test_kept_kernel_traces_agree_with_the_bench_lines():
         calls = sum(int(row["Calls"]) for row in rows)
         avg_ms = sum(float(row["TotalDurationNs"]) for row in rows) / calls / 1e6
         assert abs(avg_ms - roof["avg_launch_ms"]) / roof["avg_launch_ms"] < 0.15, (wl, avg_ms, roof["avg_launch_ms"])
+
+
+def test_kept_headline_carries_both_arithmetics():
+    """VERDICT r4 #1a: the headline line reports the opt-in contracted arithmetic beside the exact one -- time, value, parity against the exact frame and
+    against the oracle on the sample, and the executed instruction counts of both kernels from the two kept counter files."""
+    r, _ = kept_bench_lines()
+    d = json.load(open(os.path.join(PROFILES, r + "_bench_headline.json")))
+    c = d.get("contracted")
+    if c is None:
+        pytest.skip("the kept headline predates option fp_contract")
+    assert d["config"]["arith"] == "exact" and d["value_contracted"] == c["value"] > d["value"]
+    assert c["contracted_launches_per_frame"] > 0 and 1.05 < c["speedup_vs_exact"] < 1.5
+    for cmp in (c["vs_exact_frame"], c["vs_oracle_on_the_sample"]):
+        assert max(cmp["rms_per_channel"]) <= 1e-4 and cmp["bit_identical_pixels"] >= 0.999
+    for k in ("k_pt_bounce", "k_pt_shadow"):
+        assert 0.5 < c["valu_wave_instructions_per_launch"][k]["ratio"] < 0.9, k
+    # and the exact frame itself is the oracle's on the sample, bit for bit
+    assert d["cpu_baseline"]["gpu_frame_vs_oracle_on_the_sample"]["bit_identical_pixels"] == 1.0
